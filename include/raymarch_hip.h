@@ -1,0 +1,166 @@
+/*
+ * raymarch_hip.h -- C ABI of the MI355X (gfx950) sphere-tracing renderer.
+ *
+ * This is the boundary that replaces the reference's OpenGL compute dispatch
+ * (glad/GLFW context, shader compile, SSBO upload, glDispatchCompute,
+ * glGetTexImage).  Plain pointers and sizes only.  Every entry point returns
+ * RM_OK (0) or a negative rm_status; rm_last_error() gives the message of the
+ * calling thread's last failure.  The reference's operators are all void and
+ * print "[Error] ..." (render.cpp:417-425); the C++ facade in
+ * raymarching_amd/csrc/render.h keeps that behaviour on top of these codes.
+ *
+ * A context is not re-entrant: calls on one context are serialised by the
+ * caller (the reference keeps all of this state in namespace-scope globals,
+ * render.cpp:32-46).  Different contexts may be used from different threads.
+ */
+#ifndef RAYMARCH_HIP_H
+#define RAYMARCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rm_status {
+    RM_OK = 0,
+    RM_ERR_INVALID = -1,   /* bad argument / malformed scene description   */
+    RM_ERR_HIP = -2,       /* a HIP runtime call failed (message has which) */
+    RM_ERR_STATE = -3,     /* call order: no scene / no params set yet      */
+    RM_ERR_IO = -4         /* file could not be read / written              */
+} rm_status;
+
+/* Body::Type, /root/reference/source/include/body.h:10-15 */
+typedef enum rm_body_type { RM_LIST = 0, RM_SPHERE = 1, RM_BOX = 2, RM_CROSS = 3 } rm_body_type;
+/* Body::Mode, /root/reference/source/include/body.h:17-22 */
+typedef enum rm_list_mode { RM_UNION = 0, RM_COMPLEMENT = 1, RM_INTERSECTION = 2, RM_DIFFERENCE = 3 } rm_list_mode;
+
+/*
+ * One node of the CSG tree.  The scene is the depth-first pre-order listing of
+ * scene::tree: the root list first, every list followed by its child_count
+ * children (recursively).  Replaces the fixed-stride tables built by
+ * render::shader::genscene / packbody (render.cpp:246-274, 294-366):
+ * no 1024-bodies / 1024-nodes / 64-lists limits.
+ */
+typedef struct rm_node {
+    uint32_t type;         /* rm_body_type                                     */
+    uint32_t mode;         /* lists: rm_list_mode                              */
+    uint32_t child_count;  /* lists: number of direct children                 */
+    float    center[3];    /* primitives: position                             */
+    float    size[3];      /* box, cross: full edge lengths; sphere: size[0] = radius */
+    float    color[3];     /* primitives: colour                               */
+} rm_node;
+
+/*
+ * Render constants: the uniforms of render::pushuniforms (render.cpp:368-391),
+ * i.e. /root/reference/source/include/constants.h:11-27 made run-time values.
+ */
+typedef struct rm_params {
+    uint32_t width;        /* constants::width            */
+    uint32_t height;       /* constants::height           */
+    uint32_t kernel;       /* constants::SSAA::kernel     */
+    int32_t  iterations;   /* constants::iterations       */
+    float    saturation;   /* constants::saturation       */
+    float    surface_eps;  /* constants::precision::surface */
+    float    offset_eps;   /* constants::precision::offset  */
+} rm_params;
+
+/*
+ * Row bands of the image rendered by one call: rows are grouped in bands of
+ * band_rows; the call renders bands first_band, first_band + band_stride, ...
+ * (band_count of them) into a compact buffer of band_count * band_rows rows.
+ * {height, 0, 1, 1} is the whole frame.  Used to shard one frame over GPUs.
+ */
+typedef struct rm_rows {
+    uint32_t band_rows;
+    uint32_t first_band;
+    uint32_t band_stride;
+    uint32_t band_count;
+} rm_rows;
+
+/* Work counters of the last render (filled only when counting is enabled). */
+typedef struct rm_counters {
+    uint64_t sdf_calls;    /* scene SDF evaluations (march steps + 6 per gradient) */
+    uint64_t march_steps;  /* iterations of the sphere-tracing loop                 */
+    uint64_t rays;         /* primary + shadow rays                                 */
+    uint64_t prims;        /* primitives in the uploaded scene                      */
+    double   kernel_ms;    /* device time of the trace kernel(s), HIP events        */
+    double   resolve_ms;   /* device time of the resolve kernel                     */
+} rm_counters;
+
+typedef struct rm_context rm_context;
+
+/* Replaces render::setup::context / shaders / buffers (render.cpp:408-445):
+ * selects the HIP device, creates the stream, checks the kernels are loadable. */
+int rm_create(int device, rm_context **out);
+
+/* Replaces render::destroy (render.cpp:477-479). */
+int rm_destroy(rm_context *ctx);
+
+/* Replaces render::pushuniforms (render.cpp:368-391). */
+int rm_set_params(rm_context *ctx, const rm_params *params);
+
+/* Replaces render::push's scene part: genscene + genlights + 3x pushssbo and the
+ * camera uniforms (render.cpp:393-404, 447-466).  transform is the camera's
+ * 4x4 matrix, column-major (packmatrix, render.cpp:281-286). */
+int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes,
+                 const float *lights_xyz, uint32_t n_lights,
+                 const float transform[16], float focal);
+
+/* Replaces render::GPU (render.cpp:468-475): renders the whole frame and
+ * copies it into the caller's host buffer, width*height*4 bytes, row 0 = top,
+ * RGBA8 = round(clamp(c,0,1)*255), alpha 255. */
+int rm_render_rgba8(rm_context *ctx, uint8_t *host_image);
+
+/* Same frame as float RGBA (the CPU operators' Image2D<float4>, render.cpp:119),
+ * width*height*4 floats. */
+int rm_render_f32(rm_context *ctx, float *host_image);
+
+/* Renders the given row bands into caller-owned DEVICE buffers (either may be
+ * NULL): device_f32 holds rows*width*4 floats, device_rgba8 rows*width*4 bytes,
+ * rows = band_count*band_rows.  Work is queued on the context's stream; the
+ * call returns after the stream has been synchronised. */
+int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8);
+
+/* Scene SDF at n host points (xyz interleaved): signed distance and the index
+ * (depth-first primitive order) of the primitive whose colour wins.  Exposes
+ * the device evaluator of Body::List::SDF (body.cpp:66-111) for parity tests. */
+int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim);
+
+/* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
+int rm_set_counting(rm_context *ctx, int enabled);
+int rm_get_counters(rm_context *ctx, rm_counters *out);
+
+/* The context's HIP stream (hipStream_t) for callers that time with HIP events. */
+void *rm_stream(rm_context *ctx);
+
+const char *rm_last_error(void);
+
+/* ---- host scene library (scene::load and the generators), C view ---------- */
+
+typedef struct rm_scene rm_scene;
+
+/* scene::load (scene.cpp:92-190): parses an objects.txt file into a tree.
+ * A missing file gives an empty scene, as the reference does. */
+int rm_scene_load(const char *path, rm_scene **out);
+int rm_scene_parse(const char *text, rm_scene **out);
+void rm_scene_free(rm_scene *scene);
+
+uint32_t rm_scene_node_count(const rm_scene *scene);
+uint32_t rm_scene_light_count(const rm_scene *scene);
+/* Copies the pre-order node list / light positions / camera of the scene. */
+int rm_scene_nodes(const rm_scene *scene, rm_node *out, uint32_t capacity);
+int rm_scene_lights(const rm_scene *scene, float *out_xyz, uint32_t capacity);
+int rm_scene_camera(const rm_scene *scene, float transform[16], float *focal);
+
+/* rm_set_scene from a loaded scene. */
+int rm_set_scene_from(rm_context *ctx, const rm_scene *scene);
+
+/* Writes an RGBA8 image as a PNG file (stored/deflate-less zlib stream). */
+int rm_write_png(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""ctypes declarations for include/raymarch_hip.h and thin owning wrappers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch_hip.so")
+
+# every symbol include/raymarch_hip.h declares
+EXPORTS = (
+    "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
+    "rm_render_device", "rm_eval_sdf", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
+    "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
+)
+
+
+class RaymarchError(RuntimeError):
+    pass
+
+
+class Node(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("mode", C.c_uint32), ("child_count", C.c_uint32),
+                ("center", C.c_float * 3), ("size", C.c_float * 3), ("color", C.c_float * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("kernel", C.c_uint32),
+                ("iterations", C.c_int32), ("saturation", C.c_float),
+                ("surface_eps", C.c_float), ("offset_eps", C.c_float)]
+
+
+class Rows(C.Structure):
+    _fields_ = [("band_rows", C.c_uint32), ("first_band", C.c_uint32),
+                ("band_stride", C.c_uint32), ("band_count", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
+                ("prims", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads libraymarch_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaymarchError(
+            f"{LIB_PATH} is missing: build it with `make -C raymarching_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rm_last_error.restype = C.c_char_p
+    L.rm_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rm_destroy.argtypes = [vp]
+    L.rm_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.rm_set_scene.argtypes = [vp, C.POINTER(Node), C.c_uint32, vp, C.c_uint32, vp, C.c_float]
+    L.rm_render_rgba8.argtypes = [vp, vp]
+    L.rm_render_f32.argtypes = [vp, vp]
+    L.rm_render_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.rm_set_counting.argtypes = [vp, C.c_int]
+    L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.rm_stream.argtypes = [vp]
+    L.rm_stream.restype = vp
+    L.rm_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rm_scene_parse.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rm_scene_free.argtypes = [vp]
+    L.rm_scene_free.restype = None
+    L.rm_scene_node_count.argtypes = [vp]
+    L.rm_scene_node_count.restype = C.c_uint32
+    L.rm_scene_light_count.argtypes = [vp]
+    L.rm_scene_light_count.restype = C.c_uint32
+    L.rm_scene_nodes.argtypes = [vp, C.POINTER(Node), C.c_uint32]
+    L.rm_scene_lights.argtypes = [vp, vp, C.c_uint32]
+    L.rm_scene_camera.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.rm_set_scene_from.argtypes = [vp, vp]
+    L.rm_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names from EXPORTS the loaded library really exports."""
+    L = lib()
+    return [n for n in EXPORTS if hasattr(L, n)]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RaymarchError(f"{what} failed ({rc}): {lib().rm_last_error().decode(errors='replace')}")
+
+
+def default_params(**over):
+    """The reference's constants.h values."""
+    p = Params(1024, 768, 3, 1000, 0.05, 1e-3, 1e-3)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Scene:
+    """Host scene parsed by the library's C++ loader (scene::load)."""
+
+    def __init__(self, path=None, text=None):
+        self._h = C.c_void_p()
+        if text is not None:
+            _check(lib().rm_scene_parse(text.encode(), C.byref(self._h)), "rm_scene_parse")
+        else:
+            _check(lib().rm_scene_load(os.fsencode(path), C.byref(self._h)), "rm_scene_load")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rm_scene_free(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def nodes(self):
+        n = lib().rm_scene_node_count(self._h)
+        arr = (Node * n)()
+        _check(lib().rm_scene_nodes(self._h, arr, n), "rm_scene_nodes")
+        return arr
+
+    def lights(self):
+        n = lib().rm_scene_light_count(self._h)
+        out = np.zeros((n, 3), np.float32)
+        _check(lib().rm_scene_lights(self._h, out.ctypes.data, n), "rm_scene_lights")
+        return out
+
+    def camera(self):
+        t = np.zeros(16, np.float32)
+        f = C.c_float()
+        _check(lib().rm_scene_camera(self._h, t.ctypes.data, C.byref(f)), "rm_scene_camera")
+        return t, np.float32(f.value)
+
+
+class Renderer:
+    """Owning wrapper of an rm_context."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().rm_create(device, C.byref(self._h)), "rm_create")
+        self.params = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_params(self, params):
+        _check(lib().rm_set_params(self._h, C.byref(params)), "rm_set_params")
+        self.params = params
+
+    def set_scene(self, scene):
+        _check(lib().rm_set_scene_from(self._h, scene.handle), "rm_set_scene_from")
+
+    def set_scene_raw(self, nodes, lights, transform, focal):
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 3)
+        transform = np.ascontiguousarray(transform, np.float32)
+        arr = (Node * len(nodes))(*nodes) if not isinstance(nodes, C.Array) else nodes
+        _check(lib().rm_set_scene(self._h, arr, len(arr), lights.ctypes.data, len(lights),
+                                  transform.ctypes.data, C.c_float(focal)), "rm_set_scene")
+
+    def render_f32(self):
+        p = self.params
+        out = np.zeros((p.height, p.width, 4), np.float32)
+        _check(lib().rm_render_f32(self._h, out.ctypes.data), "rm_render_f32")
+        return out
+
+    def render_rgba8(self):
+        p = self.params
+        out = np.zeros((p.height, p.width, 4), np.uint8)
+        _check(lib().rm_render_rgba8(self._h, out.ctypes.data), "rm_render_rgba8")
+        return out
+
+    def render_device(self, rows, f32_ptr=None, rgba8_ptr=None):
+        """rows: Rows; pointers are raw device addresses (e.g. torch.Tensor.data_ptr())."""
+        _check(lib().rm_render_device(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_render_device")
+
+    def eval_sdf(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        sd = np.zeros(len(xyz), np.float32)
+        prim = np.zeros(len(xyz), np.uint32)
+        _check(lib().rm_eval_sdf(self._h, xyz.ctypes.data, len(xyz), sd.ctypes.data, prim.ctypes.data), "rm_eval_sdf")
+        return sd, prim
+
+    def set_counting(self, enabled):
+        _check(lib().rm_set_counting(self._h, int(bool(enabled))), "rm_set_counting")
+
+    def counters(self):
+        c = Counters()
+        _check(lib().rm_get_counters(self._h, C.byref(c)), "rm_get_counters")
+        return c.as_dict()
+
+    @property
+    def stream(self):
+        return lib().rm_stream(self._h)
+
+
+def write_png(path, rgba):
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w = rgba.shape[:2]
+    _check(lib().rm_write_png(os.fsencode(path), rgba.ctypes.data, w, h), "rm_write_png")

@@ -1,0 +1,355 @@
+// api.cpp -- the C ABI of include/raymarch_hip.h on top of the kernels.
+//
+// Takes the place of the reference's OpenGL host code: context/shader/buffer
+// setup (render.cpp:408-445), scene + uniform upload (render.cpp:368-405,
+// 447-466) and dispatch + read-back (render.cpp:468-475).
+#include "../../include/raymarch_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+#include "scene.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(rm_status code, const std::string &what) {
+    g_error = what;
+    return code;
+}
+
+#define RM_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(RM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+template <typename T>
+struct DeviceArray {
+    T *ptr = nullptr;
+    size_t capacity = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= capacity && ptr) return hipSuccess;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            ptr = nullptr;
+            capacity = 0;
+            if (e != hipSuccess) return e;
+        }
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+        if (e == hipSuccess) capacity = n;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+    }
+};
+
+}  // namespace
+
+struct rm_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+
+    bool have_params = false, have_scene = false, counting = false;
+    rm_params params{};
+    rmdev::HostProgram program;
+    rmdev::SceneView scene{};
+
+    DeviceArray<rmdev::Op> d_ops;
+    DeviceArray<rmdev::Float4> d_pa, d_pb, d_colors, d_lights, d_samples;
+    DeviceArray<float> d_frame_f32;
+    DeviceArray<unsigned char> d_frame_rgba8;
+    DeviceArray<rmdev::WorkCounters> d_counters;
+    DeviceArray<float> d_points, d_sd;
+    DeviceArray<uint32_t> d_prim;
+
+    rm_counters last{};
+};
+
+namespace {
+
+int check_ready(rm_context *ctx) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (!ctx->have_params) return fail(RM_ERR_STATE, "rm_set_params has not been called");
+    if (!ctx->have_scene) return fail(RM_ERR_STATE, "rm_set_scene has not been called");
+    return RM_OK;
+}
+
+rmdev::FrameView frame_view(const rm_params &p, const rm_rows &rows) {
+    rmdev::FrameView f{};
+    f.width = p.width; f.height = p.height; f.kernel = p.kernel; f.iterations = p.iterations;
+    f.saturation = p.saturation; f.surface_eps = p.surface_eps; f.offset_eps = p.offset_eps;
+    f.band_rows = rows.band_rows; f.first_band = rows.first_band;
+    f.band_stride = rows.band_stride; f.band_count = rows.band_count;
+    return f;
+}
+
+// Trace + resolve of the given bands into device buffers; synchronises the stream.
+int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8) {
+    if (rows.band_rows == 0 || rows.band_count == 0 || rows.band_stride == 0)
+        return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
+    RM_HIP(hipSetDevice(ctx->device));
+    const rmdev::FrameView fr = frame_view(ctx->params, rows);
+    RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
+    rmdev::WorkCounters *d_cnt = nullptr;
+    if (ctx->counting) {
+        RM_HIP(ctx->d_counters.reserve(1));
+        d_cnt = ctx->d_counters.ptr;
+        RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
+    }
+    RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
+    RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
+    RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    float ms_trace = 0.0f, ms_resolve = 0.0f;
+    RM_HIP(hipEventElapsedTime(&ms_trace, ctx->ev[0], ctx->ev[1]));
+    RM_HIP(hipEventElapsedTime(&ms_resolve, ctx->ev[1], ctx->ev[2]));
+    ctx->last = rm_counters{};
+    ctx->last.kernel_ms = ms_trace;
+    ctx->last.resolve_ms = ms_resolve;
+    ctx->last.prims = ctx->program.n_prims;
+    if (ctx->counting) {
+        rmdev::WorkCounters h{};
+        RM_HIP(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
+        ctx->last.sdf_calls = h.sdf_calls;
+        ctx->last.march_steps = h.march_steps;
+        ctx->last.rays = h.rays;
+    }
+    return RM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rm_last_error(void) { return g_error.c_str(); }
+
+int rm_create(int device, rm_context **out) {
+    if (!out) return fail(RM_ERR_INVALID, "rm_create: null output pointer");
+    *out = nullptr;
+    int n_devices = 0;
+    RM_HIP(hipGetDeviceCount(&n_devices));
+    if (device < 0 || device >= n_devices)
+        return fail(RM_ERR_INVALID, "rm_create: no HIP device with ordinal " + std::to_string(device) + " (" +
+                                        std::to_string(n_devices) + " visible)");
+    RM_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RM_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RM_ERR_HIP, std::string("rm_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    rm_context *ctx = new (std::nothrow) rm_context();
+    if (!ctx) return fail(RM_ERR_INVALID, "rm_create: out of host memory");
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        rm_destroy(ctx);
+        return fail(RM_ERR_HIP, std::string("rm_create: ") + hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RM_OK;
+}
+
+int rm_destroy(rm_context *ctx) {
+    if (!ctx) return RM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_ops.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
+    ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
+    ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
+    ctx->d_sd.release(); ctx->d_prim.release();
+    for (int i = 0; i < 3; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RM_OK;
+}
+
+int rm_set_params(rm_context *ctx, const rm_params *params) {
+    if (!ctx || !params) return fail(RM_ERR_INVALID, "rm_set_params: null argument");
+    if (params->width == 0 || params->height == 0 || params->kernel == 0)
+        return fail(RM_ERR_INVALID, "rm_set_params: width, height and kernel must be positive");
+    if ((uint64_t)params->width * params->kernel > 0x7fffffffull || (uint64_t)params->height * params->kernel > 0x7fffffffull)
+        return fail(RM_ERR_INVALID, "rm_set_params: image too large");
+    ctx->params = *params;
+    ctx->have_params = true;
+    return RM_OK;
+}
+
+int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const float *lights_xyz, uint32_t n_lights,
+                 const float transform[16], float focal) {
+    if (!ctx || !transform) return fail(RM_ERR_INVALID, "rm_set_scene: null argument");
+    if (n_lights && !lights_xyz) return fail(RM_ERR_INVALID, "rm_set_scene: lights pointer is null");
+    std::string why;
+    rmdev::HostProgram prog;
+    if (!rmdev::compile_scene(nodes, n_nodes, prog, why)) return fail(RM_ERR_INVALID, "rm_set_scene: " + why);
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(ctx->d_ops.reserve(prog.ops.size()));
+    RM_HIP(ctx->d_pa.reserve(prog.pa.size()));
+    RM_HIP(ctx->d_pb.reserve(prog.pb.size()));
+    RM_HIP(ctx->d_colors.reserve(prog.colors.size()));
+    RM_HIP(ctx->d_lights.reserve(n_lights));
+    std::vector<rmdev::Float4> lights(n_lights ? n_lights : 1, rmdev::Float4{ 0, 0, 0, 0 });
+    for (uint32_t i = 0; i < n_lights; i++)
+        lights[i] = rmdev::Float4{ lights_xyz[3 * i], lights_xyz[3 * i + 1], lights_xyz[3 * i + 2], 0.0f };
+    RM_HIP(hipMemcpyAsync(ctx->d_ops.ptr, prog.ops.data(), prog.ops.size() * sizeof(rmdev::Op), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_pa.ptr, prog.pa.data(), prog.pa.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_pb.ptr, prog.pb.data(), prog.pb.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_colors.ptr, prog.colors.data(), prog.colors.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_lights.ptr, lights.data(), lights.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
+    ctx->program = std::move(prog);
+    rmdev::SceneView &sv = ctx->scene;
+    sv.ops = ctx->d_ops.ptr; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
+    sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
+    sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
+    std::memcpy(sv.cam, transform, sizeof sv.cam);
+    sv.focal = focal;
+    ctx->have_scene = true;
+    return RM_OK;
+}
+
+int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!rows) return fail(RM_ERR_INVALID, "rm_render_device: null rows");
+    return render_bands(ctx, *rows, device_f32, device_rgba8);
+}
+
+int rm_render_rgba8(rm_context *ctx, uint8_t *host_image) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!host_image) return fail(RM_ERR_INVALID, "rm_render_rgba8: null image");
+    const size_t bytes = (size_t)ctx->params.width * ctx->params.height * 4;
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(ctx->d_frame_rgba8.reserve(bytes));
+    const rm_rows whole = { ctx->params.height, 0, 1, 1 };
+    if (int rc = render_bands(ctx, whole, nullptr, ctx->d_frame_rgba8.ptr)) return rc;
+    RM_HIP(hipMemcpy(host_image, ctx->d_frame_rgba8.ptr, bytes, hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+
+int rm_render_f32(rm_context *ctx, float *host_image) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!host_image) return fail(RM_ERR_INVALID, "rm_render_f32: null image");
+    const size_t n = (size_t)ctx->params.width * ctx->params.height * 4;
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(ctx->d_frame_f32.reserve(n));
+    const rm_rows whole = { ctx->params.height, 0, 1, 1 };
+    if (int rc = render_bands(ctx, whole, ctx->d_frame_f32.ptr, nullptr)) return rc;
+    RM_HIP(hipMemcpy(host_image, ctx->d_frame_f32.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+
+int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (!ctx->have_scene) return fail(RM_ERR_STATE, "rm_set_scene has not been called");
+    if (n == 0) return RM_OK;
+    if (!host_xyz || !host_sd || !host_prim) return fail(RM_ERR_INVALID, "rm_eval_sdf: null argument");
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(ctx->d_points.reserve((size_t)n * 3));
+    RM_HIP(ctx->d_sd.reserve(n));
+    RM_HIP(ctx->d_prim.reserve(n));
+    RM_HIP(hipMemcpyAsync(ctx->d_points.ptr, host_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(rmdev::launch_eval_sdf(ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
+    RM_HIP(hipMemcpyAsync(host_sd, ctx->d_sd.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(hipMemcpyAsync(host_prim, ctx->d_prim.ptr, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_set_counting(rm_context *ctx, int enabled) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    ctx->counting = enabled != 0;
+    return RM_OK;
+}
+
+int rm_get_counters(rm_context *ctx, rm_counters *out) {
+    if (!ctx || !out) return fail(RM_ERR_INVALID, "rm_get_counters: null argument");
+    *out = ctx->last;
+    return RM_OK;
+}
+
+void *rm_stream(rm_context *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+// ---- host scene library ----------------------------------------------------
+
+struct rm_scene {
+    scene::Scene s;
+};
+
+int rm_scene_load(const char *path, rm_scene **out) {
+    if (!path || !out) return fail(RM_ERR_INVALID, "rm_scene_load: null argument");
+    rm_scene *sc = new (std::nothrow) rm_scene();
+    if (!sc) return fail(RM_ERR_INVALID, "rm_scene_load: out of host memory");
+    sc->s.load(path);  // a missing file leaves the scene empty, as scene::load does
+    *out = sc;
+    return RM_OK;
+}
+
+int rm_scene_parse(const char *text, rm_scene **out) {
+    if (!text || !out) return fail(RM_ERR_INVALID, "rm_scene_parse: null argument");
+    rm_scene *sc = new (std::nothrow) rm_scene();
+    if (!sc) return fail(RM_ERR_INVALID, "rm_scene_parse: out of host memory");
+    sc->s.parse(text);
+    *out = sc;
+    return RM_OK;
+}
+
+void rm_scene_free(rm_scene *scene) { delete scene; }
+
+uint32_t rm_scene_node_count(const rm_scene *scene) {
+    return scene ? static_cast<uint32_t>(scene->s.nodes().size()) : 0;
+}
+
+uint32_t rm_scene_light_count(const rm_scene *scene) {
+    return scene ? static_cast<uint32_t>(scene->s.lights.size()) : 0;
+}
+
+int rm_scene_nodes(const rm_scene *scene, rm_node *out, uint32_t capacity) {
+    if (!scene || !out) return fail(RM_ERR_INVALID, "rm_scene_nodes: null argument");
+    const std::vector<rm_node> nodes = scene->s.nodes();
+    if (capacity < nodes.size()) return fail(RM_ERR_INVALID, "rm_scene_nodes: capacity too small");
+    std::memcpy(out, nodes.data(), nodes.size() * sizeof(rm_node));
+    return RM_OK;
+}
+
+int rm_scene_lights(const rm_scene *scene, float *out_xyz, uint32_t capacity) {
+    if (!scene || (!out_xyz && capacity)) return fail(RM_ERR_INVALID, "rm_scene_lights: null argument");
+    const std::vector<float> l = scene->s.light_positions();
+    if ((size_t)capacity * 3 < l.size()) return fail(RM_ERR_INVALID, "rm_scene_lights: capacity too small");
+    if (!l.empty()) std::memcpy(out_xyz, l.data(), l.size() * sizeof(float));
+    return RM_OK;
+}
+
+int rm_scene_camera(const rm_scene *scene, float transform[16], float *focal) {
+    if (!scene || !transform || !focal) return fail(RM_ERR_INVALID, "rm_scene_camera: null argument");
+    std::memcpy(transform, scene->s.camera->transform.m, 16 * sizeof(float));
+    *focal = scene->s.camera->focal;
+    return RM_OK;
+}
+
+int rm_set_scene_from(rm_context *ctx, const rm_scene *scene) {
+    if (!ctx || !scene) return fail(RM_ERR_INVALID, "rm_set_scene_from: null argument");
+    const std::vector<rm_node> nodes = scene->s.nodes();
+    const std::vector<float> lights = scene->s.light_positions();
+    return rm_set_scene(ctx, nodes.data(), static_cast<uint32_t>(nodes.size()), lights.data(),
+                        static_cast<uint32_t>(lights.size() / 3), scene->s.camera->transform.m,
+                        scene->s.camera->focal);
+}
+
+}  // extern "C"

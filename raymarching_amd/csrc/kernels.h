@@ -1,0 +1,29 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_scene.h"
+
+namespace rmdev {
+
+// Sub-sample image: (rows * kernel) x (width * kernel) texels, one per SSAA
+// sample, rgb in xyz.  rows = band_count * band_rows.
+size_t sample_texels(const FrameView &fr);
+
+// Traces every SSAA sample of the launch's row bands (primary march, colour,
+// normal, one shadow ray per light, shading) into `samples`.
+// counters may be null (no counting).
+hipError_t launch_trace(const SceneView &sc, const FrameView &fr, Float4 *samples,
+                        WorkCounters *counters, hipStream_t stream);
+
+// Averages the kernel x kernel samples of each pixel in the reference's
+// accumulation order and writes float RGBA and/or RGBA8 (either may be null).
+hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out_f32,
+                          unsigned char *out_rgba8, hipStream_t stream);
+
+// Scene SDF with colour tracking at n points.
+hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd,
+                           uint32_t *prim, hipStream_t stream);
+
+}  // namespace rmdev

@@ -1,0 +1,27 @@
+// program.h -- host compiler from the pre-order node list (rm_node[]) to the
+// flat device program and primitive tables of device_scene.h.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/raymarch_hip.h"
+#include "device_scene.h"
+
+namespace rmdev {
+
+struct HostProgram {
+    std::vector<Op> ops;
+    std::vector<Float4> pa, pb, colors;
+    uint32_t n_prims = 0;
+    uint32_t n_lists = 0;
+    uint32_t max_depth = 0;
+    // algorithmic cost of one scene SDF evaluation: 11 per sphere, 9 per box,
+    // 15 per cross (primitive arithmetic + the one compare/select of the fold)
+    uint64_t flops_per_sdf = 0;
+};
+
+// Returns false and sets `error` if the node list is not a well-formed tree.
+bool compile_scene(const rm_node *nodes, uint32_t n_nodes, HostProgram &out, std::string &error);
+
+}  // namespace rmdev

@@ -1,0 +1,93 @@
+// render.cpp -- render::setup / push / GPU / destroy on the C ABI.
+//
+// Where the reference creates a hidden GLFW window, compiles shader.comp at run
+// time and allocates a texture plus three SSBOs (render.cpp:408-445), this
+// back-end only needs a HIP context: the kernels are compiled ahead of time for
+// gfx950 and buffers are sized on demand.  The three setup operators are kept
+// so that a caller written against the reference runs unchanged.
+#include "render.h"
+
+#include <iostream>
+#include <string>
+
+namespace constants {
+rm_params params = { 1024u, 768u, 3u, 1000, 0.05f, 1e-3f, 1e-3f };
+}
+
+namespace render {
+
+namespace {
+
+rm_context *g_ctx = nullptr;
+bool g_ok = true;
+std::string g_error;
+
+void report(int rc, const char *what) {
+    g_ok = (rc == RM_OK);
+    if (!g_ok) {
+        g_error = std::string(what) + ": " + rm_last_error();
+        std::cout << "[Error] " << g_error << std::endl;
+    }
+}
+
+bool have_context(const char *what) {
+    if (g_ctx) return true;
+    g_ok = false;
+    g_error = std::string(what) + ": render::setup::context() has not succeeded";
+    std::cout << "[Error] " << g_error << std::endl;
+    return false;
+}
+
+}  // namespace
+
+void setup::context(void) {
+    if (g_ctx) {
+        rm_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    report(rm_create(0, &g_ctx), "Failed to create HIP context");
+}
+
+// The kernels are part of the library image; there is nothing to compile or link.
+void setup::shaders(void) {
+    have_context("setup::shaders");
+}
+
+// Device buffers are sized by push() and GPU(); nothing to pre-allocate.
+void setup::buffers(void) {
+    have_context("setup::buffers");
+}
+
+void push(void) {
+    if (!have_context("push")) return;
+    int rc = rm_set_params(g_ctx, &constants::params);
+    if (rc != RM_OK) return report(rc, "Failed to upload constants");
+    const scene::Scene &sc = scene::current();
+    const std::vector<rm_node> nodes = sc.nodes();
+    const std::vector<float> lights = sc.light_positions();
+    rc = rm_set_scene(g_ctx, nodes.data(), static_cast<uint32_t>(nodes.size()), lights.data(),
+                      static_cast<uint32_t>(lights.size() / 3), sc.camera->transform.m, sc.camera->focal);
+    report(rc, "Failed to upload scene");
+}
+
+void GPU(unsigned char *image) {
+    if (!have_context("GPU")) return;
+    report(rm_render_rgba8(g_ctx, image), "Failed to render");
+}
+
+void GPU(float *image) {
+    if (!have_context("GPU")) return;
+    report(rm_render_f32(g_ctx, image), "Failed to render");
+}
+
+void destroy(void) {
+    if (g_ctx) rm_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_ok = true;
+}
+
+bool ok(void) { return g_ok; }
+const char *error(void) { return g_error.c_str(); }
+rm_context *context(void) { return g_ctx; }
+
+}  // namespace render

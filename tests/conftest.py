@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle binding (built on demand with gcc)."""
+    from oracle import rmo
+    rmo.lib()
+    return rmo
+
+
+@pytest.fixture(scope="session")
+def rm():
+    """The product binding (libraymarch_hip.so must have been built)."""
+    import raymarching_amd
+    raymarching_amd.lib()
+    return raymarching_amd
+
+
+@pytest.fixture(scope="session")
+def renderer(rm):
+    r = rm.Renderer(0)
+    yield r
+    r.close()
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name)
