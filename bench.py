@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the sphere-tracing hot path: Mrays/s (primary + shadow rays) and frame time.
+
+    python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd]
+
+A step is one frame of the workload.  At N > 1 (one process per GPU, launched by
+torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
+renders its bands into device memory and the RGBA8 bands are gathered to rank 0 with RCCL
+(the one exchange step of the path); the same frame is rendered whatever N is, so scaling
+is "strong".  Rank 0 prints ONE JSON line.
+
+    value         = frames * W*H*k*k*(1+L) rays / wall time (max over ranks), in Mrays/s
+    roofline      = algorithmic FLOPs of the trace kernel (counted scene-SDF calls x FLOPs per
+                    call + 7 per march step) / its HIP-event duration, against the fp32 vector peak
+    cpu_baseline  = the CPU oracle (a port of the reference's render::OMP / render::CPU) timed on
+                    this host on a stated row sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (first: the renderer must share torch's HIP runtime)
+import torch.distributed as dist  # noqa: E402
+
+import raymarching_amd as rm  # noqa: E402
+from raymarching_amd import sharding  # noqa: E402
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet (packed FMA); see DESIGN.md for the non-fused limit
+WORKLOADS = {
+    # name: (scene file, params overrides, description)
+    "default": ("default.txt", dict(), "configs[1]: shipped scene (Menger iterations 3), 1024x768, SSAA 3x3, 2 lights"),
+    "menger2": ("menger2.txt", dict(kernel=1), "configs[0]: Menger iterations 2, 1024x768, SSAA 1, 2 lights"),
+    "uhd": ("default.txt", dict(width=3840, height=2160, kernel=4), "configs[2]: shipped scene, 3840x2160, SSAA 4x4, 2 lights"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS))
+    ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_file, kw):
+    """Times the oracle on a bounded row sample of the workload; returns the JSON object."""
+    from oracle import rmo
+    sc = rmo.Scene(scene_file)
+    p = rmo.default_params(**kw)
+    threads = rmo.max_threads()
+    lights = sc.light_count
+    step = max(1, p.height // 24)
+    rows = (step // 2, p.height, step)                 # ~24 rows spread over the frame
+    t0 = time.perf_counter()
+    _, cnt = sc.render(p, rows=rows, threads=threads)
+    t_omp = time.perf_counter() - t0
+    rows1 = (step // 2 + 8 * step, p.height, 8 * step)  # ~3 of those rows for the serial loop
+    t0 = time.perf_counter()
+    _, cnt1 = sc.render(p, rows=rows1, threads=1)
+    t_1 = time.perf_counter() - t0
+    n_rows = len(range(*rows))
+    n_rows1 = len(range(*rows1))
+    return {
+        "value": round(cnt["rays"] / t_omp / 1e6, 5), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"render::OMP restatement on rows {rows[0]}::{rows[2]} ({n_rows} of {p.height} rows, "
+                  f"{cnt['rays']} rays, {cnt['sdf_calls']} SDF calls) in {t_omp:.2f} s",
+        "single_thread": {
+            "value": round(cnt1["rays"] / t_1 / 1e6, 5), "unit": "Mrays/s", "cores": 1,
+            "sample": f"render::CPU restatement on rows {rows1[0]}::{rows1[2]} ({n_rows1} rows, {cnt1['rays']} rays) in {t_1:.2f} s",
+        },
+        "lights": lights,
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    scene_name, kw, desc = WORKLOADS[a.workload]
+    scene_file = os.path.join(ROOT, "scenes", scene_name)
+    params = rm.default_params(**kw)
+    scene = rm.Scene(scene_file)
+    n_lights = len(scene.lights())
+    r = rm.Renderer(local)
+    r.set_params(params)
+    r.set_scene(scene)
+
+    W, H, k = params.width, params.height, params.kernel
+    rays_per_frame = W * H * k * k * (1 + n_lights)
+
+    # ---- sharding: bands of band_rows rows, band b belongs to rank b % world
+    rows, local_rows = sharding.band_plan(H, a.band_rows, world, rank)
+    shard = torch.empty((local_rows, W, 4), dtype=torch.uint8, device="cuda")
+    gathered = [torch.empty_like(shard) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def frame():
+        r.render_device(rows, None, shard.data_ptr())
+        return sharding.gather_frame(shard, H, a.band_rows, world, rank, gathered)
+
+    # ---- work count of this rank's share (instrumented kernel, outside the timed region)
+    r.set_counting(True)
+    frame()
+    cnt = r.counters()
+    r.set_counting(False)
+    # algorithmic FLOPs per scene SDF call: 11 per sphere, 9 per box, 15 per cross
+    types = [n.type for n in scene.nodes()]
+    flops_per_sdf = 11 * types.count(1) + 9 * types.count(2) + 15 * types.count(3)
+    local_flops = cnt["sdf_calls"] * flops_per_sdf + 7 * cnt["march_steps"]
+
+    for _ in range(a.warmup):
+        frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = frame()
+        kernel_ms += r.counters()["kernel_ms"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms /= max(1, a.steps)
+
+    stats = torch.tensor([elapsed, kernel_ms, float(local_flops), float(cnt["sdf_calls"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        kernel_ms_max = float(mx[1])
+        total_flops, total_sdf = float(sm[2]), float(sm[3])
+    else:
+        kernel_ms_max, total_flops, total_sdf = kernel_ms, float(local_flops), float(cnt["sdf_calls"])
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = rays_per_frame * a.steps / elapsed / 1e6
+        # dominant kernel: the trace kernel of THIS rank (rank 0), its own flops over its own duration
+        achieved = local_flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Mrays/s (primary+shadow), default scene", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "scene": scene_name, "width": W, "height": H, "ssaa_kernel": k,
+                       "lights": n_lights, "primitives": cnt["prims"], "rays_per_frame": rays_per_frame,
+                       "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows}, cyclic over {world} ranks, RCCL gather of RGBA8 to rank 0"},
+            "roofline": {
+                "bound": "valu_fp32", "kernel": "trace_kernel", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel_ms": round(kernel_ms, 4), "flops_per_sdf_call": flops_per_sdf,
+                "sdf_calls_per_frame": int(total_sdf), "flops_per_frame": int(total_flops),
+                "note": "peak is the packed-FMA datasheet figure; this path has no multiply-adds to fuse (see DESIGN.md)",
+            },
+            "frame_ms": round(ms_per_step, 4),
+            "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene_file, kw)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # A process must hold ONE HIP runtime.  PyTorch ships its own libamdhip64 (SONAME
+    # libamdhip64.so.7); when torch is imported first, the dynamic loader resolves this library's
+    # dependency of the same SONAME to that copy, and tensors, streams and RCCL buffers can be
+    # shared with the renderer.  Loaded the other way round the process ends up with two runtimes
+    # and torch finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RaymarchError(
             f"{LIB_PATH} is missing: build it with `make -C raymarching_amd/csrc` "

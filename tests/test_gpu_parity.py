@@ -130,6 +130,26 @@ def test_default_scene_rows_bit_identical(rm, oracle, renderer):
     assert_bit_identical(gpu[sel], cpu[sel])
 
 
+def test_default_scene_full_frame_hash(rm, renderer):
+    """configs[1] at full size: the float frame hashes to the oracle's full-frame hash (the oracle's
+    frame is itself pixel-exact against the reference's out_cpu.png, see make_golden.py)."""
+    import hashlib
+    import json
+    rec = json.load(open(os.path.join(GOLDEN, "default_1024x768_k3.json")))
+    renderer.set_params(rm.default_params())
+    renderer.set_scene(rm.Scene(scene_path("default.txt")))
+    renderer.set_counting(True)
+    try:
+        img = renderer.render_f32()
+        c = renderer.counters()
+    finally:
+        renderer.set_counting(False)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == rec["sha256_f32"]
+    assert hashlib.sha256(renderer.render_rgba8().tobytes()).hexdigest() == rec["sha256_rgba8"]
+    for key in ("sdf_calls", "march_steps", "rays"):
+        assert c[key] == rec["counters"][key]
+
+
 def test_default_scene_against_reference_png(rm, renderer):
     """The reference's own CPU render: >= 99.9 % of pixels within 1/255 per channel (tolerance of the task)."""
     from PIL import Image
