@@ -85,6 +85,7 @@ typedef struct rm_counters {
     uint64_t march_steps;  /* iterations of the sphere-tracing loop                 */
     uint64_t rays;         /* primary + shadow rays                                 */
     uint64_t prims;        /* primitives in the uploaded scene                      */
+    uint64_t prim_evals;   /* primitive distance evaluations actually executed      */
     double   kernel_ms;    /* device time of the trace kernel(s), HIP events        */
     double   resolve_ms;   /* device time of the resolve kernel                     */
 } rm_counters;
@@ -127,6 +128,18 @@ int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, ui
  * (depth-first primitive order) of the primitive whose colour wins.  Exposes
  * the device evaluator of Body::List::SDF (body.cpp:66-111) for parity tests. */
 int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim);
+
+/*
+ * How runs of primitives are evaluated (no counterpart in the reference, whose two back-ends
+ * always visit every primitive).  Both give bit-identical frames.
+ *   RM_EVAL_EXHAUSTIVE  every primitive of the scene is evaluated at every SDF call;
+ *   RM_EVAL_LATTICE     (default) lists of cubic crosses that form a complete Menger lattice,
+ *                       as Body::MengerSponge generates (body.cpp:114-156), are recognised on
+ *                       upload and evaluated exactly by visiting only the crosses that can win.
+ * Takes effect at the next rm_set_scene.
+ */
+typedef enum rm_evaluator { RM_EVAL_EXHAUSTIVE = 0, RM_EVAL_LATTICE = 1 } rm_evaluator;
+int rm_set_evaluator(rm_context *ctx, int evaluator);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

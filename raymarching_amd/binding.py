@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_eval_sdf", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -37,7 +37,7 @@ class Rows(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
-                ("prims", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
+                ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -76,6 +76,7 @@ def lib():
     L.rm_render_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
     L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.rm_set_counting.argtypes = [vp, C.c_int]
+    L.rm_set_evaluator.argtypes = [vp, C.c_int]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rm_stream.argtypes = [vp]
     L.rm_stream.restype = vp
@@ -204,6 +205,10 @@ class Renderer:
         prim = np.zeros(len(xyz), np.uint32)
         _check(lib().rm_eval_sdf(self._h, xyz.ctypes.data, len(xyz), sd.ctypes.data, prim.ctypes.data), "rm_eval_sdf")
         return sd, prim
+
+    def set_evaluator(self, lattice):
+        """True: recognise Menger lattices (default); False: visit every primitive.  Applies to the next set_scene."""
+        _check(lib().rm_set_evaluator(self._h, 1 if lattice else 0), "rm_set_evaluator")
 
     def set_counting(self, enabled):
         _check(lib().rm_set_counting(self._h, int(bool(enabled))), "rm_set_counting")

@@ -65,6 +65,7 @@ struct rm_context {
     hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 
     bool have_params = false, have_scene = false, counting = false;
+    int evaluator = RM_EVAL_LATTICE;
     rm_params params{};
     rmdev::HostProgram program;
     rmdev::SceneView scene{};
@@ -75,7 +76,7 @@ struct rm_context {
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
     DeviceArray<float> d_points, d_sd;
-    DeviceArray<uint32_t> d_prim;
+    DeviceArray<uint32_t> d_prim, d_lattice;
 
     rm_counters last{};
 };
@@ -130,6 +131,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         ctx->last.sdf_calls = h.sdf_calls;
         ctx->last.march_steps = h.march_steps;
         ctx->last.rays = h.rays;
+        ctx->last.prim_evals = h.prim_evals;
     }
     return RM_OK;
 }
@@ -173,7 +175,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_ops.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
     ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
-    ctx->d_sd.release(); ctx->d_prim.release();
+    ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -198,13 +200,14 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     if (n_lights && !lights_xyz) return fail(RM_ERR_INVALID, "rm_set_scene: lights pointer is null");
     std::string why;
     rmdev::HostProgram prog;
-    if (!rmdev::compile_scene(nodes, n_nodes, prog, why)) return fail(RM_ERR_INVALID, "rm_set_scene: " + why);
+    if (!rmdev::compile_scene(nodes, n_nodes, ctx->evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_set_scene: " + why);
     RM_HIP(hipSetDevice(ctx->device));
     RM_HIP(ctx->d_ops.reserve(prog.ops.size()));
     RM_HIP(ctx->d_pa.reserve(prog.pa.size()));
     RM_HIP(ctx->d_pb.reserve(prog.pb.size()));
     RM_HIP(ctx->d_colors.reserve(prog.colors.size()));
     RM_HIP(ctx->d_lights.reserve(n_lights));
+    RM_HIP(ctx->d_lattice.reserve(prog.lattice.size()));
     std::vector<rmdev::Float4> lights(n_lights ? n_lights : 1, rmdev::Float4{ 0, 0, 0, 0 });
     for (uint32_t i = 0; i < n_lights; i++)
         lights[i] = rmdev::Float4{ lights_xyz[3 * i], lights_xyz[3 * i + 1], lights_xyz[3 * i + 2], 0.0f };
@@ -213,12 +216,15 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(hipMemcpyAsync(ctx->d_pb.ptr, prog.pb.data(), prog.pb.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_colors.ptr, prog.colors.data(), prog.colors.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_lights.ptr, lights.data(), lights.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_lattice.ptr, prog.lattice.data(), prog.lattice.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
     ctx->program = std::move(prog);
     rmdev::SceneView &sv = ctx->scene;
     sv.ops = ctx->d_ops.ptr; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
+    sv.lattice = ctx->d_lattice.ptr;
+    sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     std::memcpy(sv.cam, transform, sizeof sv.cam);
     sv.focal = focal;
     ctx->have_scene = true;
@@ -269,6 +275,14 @@ int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_
     RM_HIP(hipMemcpyAsync(host_sd, ctx->d_sd.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipMemcpyAsync(host_prim, ctx->d_prim.ptr, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_set_evaluator(rm_context *ctx, int evaluator) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (evaluator != RM_EVAL_EXHAUSTIVE && evaluator != RM_EVAL_LATTICE)
+        return fail(RM_ERR_INVALID, "rm_set_evaluator: unknown evaluator");
+    ctx->evaluator = evaluator;
     return RM_OK;
 }
 

@@ -6,17 +6,167 @@
 // Here the walk is done once on the host: list modes, "first child" cases and
 // nesting slots are resolved into the operations (see device_scene.h), so the
 // kernels only stream runs of same-kind primitives.
+//
+// Runs of cubic crosses that form a complete Menger lattice (what
+// Body::MengerSponge generates, body.cpp:114-156) are recognised on the node
+// data itself and compiled to a LATTICE operation, which the kernels evaluate
+// exactly without visiting every cross.
 #include "program.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace rmdev {
 
 namespace {
 
+uint32_t bits_of(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, sizeof u);
+    return u;
+}
+
+// The 20 kept sub-cubes of one subdivision step as base-3 digit triples
+// (digit = offset + 1), in the generator's order (body.cpp:122-145).
+const uint8_t kKept[20][3] = {
+    { 2, 0, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 2, 2, 0 }, { 1, 2, 0 }, { 0, 2, 0 }, { 0, 1, 0 }, { 2, 1, 0 },
+    { 2, 0, 2 }, { 1, 0, 2 }, { 0, 0, 2 }, { 2, 2, 2 }, { 1, 2, 2 }, { 0, 2, 2 }, { 0, 1, 2 }, { 2, 1, 2 },
+    { 0, 0, 1 }, { 2, 0, 1 }, { 0, 2, 1 }, { 2, 2, 1 },
+};
+
+uint32_t pow3(uint32_t l) {
+    uint32_t r = 1;
+    while (l--) r *= 3;
+    return r;
+}
+
+// number of crosses of a complete lattice with n levels: 1 + 20 + ... + 20^(n-1)
+uint64_t lattice_size(uint32_t n) {
+    uint64_t total = 0, level = 1;
+    for (uint32_t l = 0; l < n; l++) {
+        total += level;
+        level *= 20;
+    }
+    return total;
+}
+
+// Checks that nodes[at .. at + lattice_size(n)) are a complete Menger lattice of n
+// levels and, if so, fills its coordinate tables from the nodes.
+struct LatticeMatcher {
+    const rm_node *nodes;
+    uint32_t n;
+    uint32_t cursor;
+    std::vector<float> X[kLatticeMaxLevels], Y[kLatticeMaxLevels], Z[kLatticeMaxLevels];
+    std::vector<uint8_t> setx[kLatticeMaxLevels], sety[kLatticeMaxLevels], setz[kLatticeMaxLevels];
+    float half[kLatticeMaxLevels];
+    bool half_set[kLatticeMaxLevels];
+
+    static bool put(std::vector<float> &tab, std::vector<uint8_t> &set, uint32_t i, float v) {
+        if (set[i]) return bits_of(tab[i]) == bits_of(v);
+        tab[i] = v;
+        set[i] = 1;
+        return true;
+    }
+
+    bool visit(uint32_t level, uint32_t ix, uint32_t iy, uint32_t iz) {
+        const rm_node &c = nodes[cursor++];
+        if (c.type != RM_CROSS || c.size[0] != c.size[1] || c.size[1] != c.size[2]) return false;
+        if (std::memcmp(c.color, nodes[0].color, sizeof c.color) != 0) return false;
+        const float h = c.size[0] / 2;
+        if (!half_set[level]) {
+            half[level] = h;
+            half_set[level] = true;
+        } else if (bits_of(half[level]) != bits_of(h)) {
+            return false;
+        }
+        if (!put(X[level], setx[level], ix, c.center[0]) || !put(Y[level], sety[level], iy, c.center[1]) ||
+            !put(Z[level], setz[level], iz, c.center[2]))
+            return false;
+        if (level + 1 < n) {
+            for (const uint8_t *k : kKept)
+                if (!visit(level + 1, 3 * ix + k[0], 3 * iy + k[1], 3 * iz + k[2])) return false;
+        }
+        return true;
+    }
+
+    static bool evenly_spaced(const std::vector<float> &t, float &spacing) {
+        if (t.size() < 2) {
+            spacing = 0.0f;
+            return true;
+        }
+        const double step = ((double)t.back() - (double)t.front()) / (double)(t.size() - 1);
+        if (!(step > 0.0) || !std::isfinite(step)) return false;
+        for (size_t i = 0; i < t.size(); i++) {
+            if (i && !(t[i - 1] < t[i])) return false;
+            if (std::fabs((double)t[i] - ((double)t.front() + step * (double)i)) > 0.01 * step) return false;
+        }
+        spacing = (float)step;
+        return true;
+    }
+
+    // nodes must point at the first cross; returns true on a verified match
+    bool match(uint32_t levels) {
+        n = levels;
+        cursor = 0;
+        for (uint32_t l = 0; l < n; l++) {
+            const uint32_t m = pow3(l);
+            X[l].assign(m, 0.0f); Y[l].assign(m, 0.0f); Z[l].assign(m, 0.0f);
+            setx[l].assign(m, 0); sety[l].assign(m, 0); setz[l].assign(m, 0);
+            half_set[l] = false;
+        }
+        if (!visit(0, 0, 0, 0)) return false;
+        for (uint32_t l = 0; l < n; l++) {
+            if (!(half[l] > 0.0f) || !std::isfinite(half[l])) return false;
+            if (l && !(half[l] < half[l - 1])) return false;
+            float sx, sy, sz;
+            if (!evenly_spaced(X[l], sx) || !evenly_spaced(Y[l], sy) || !evenly_spaced(Z[l], sz)) return false;
+            if (l) {
+                // one spacing per level is used for the index estimate; bars of one level must not overlap
+                const float s = sx;
+                if (std::fabs(sy - s) > 0.01f * s || std::fabs(sz - s) > 0.01f * s) return false;
+                if (!(2.0f * half[l] < s)) return false;
+            }
+        }
+        return true;
+    }
+
+    // appends the lattice block (device_scene.h) and returns its word offset
+    uint32_t emit(std::vector<uint32_t> &out) const {
+        const uint32_t base = (uint32_t)out.size();
+        out.resize(base + kLatHeaderWords, 0u);
+        auto put_f = [&](uint32_t at, float v) { out[at] = bits_of(v); };
+        out[base + 0] = n;
+        double bound = 0.0;
+        for (uint32_t l = 0; l < n; l++) {
+            put_f(base + kLatHalf + l, half[l]);
+            float spacing = 0.0f;
+            if (X[l].size() > 1) spacing = (X[l].back() - X[l].front()) / (float)(X[l].size() - 1);
+            put_f(base + kLatInvSpacing + l, spacing > 0.0f ? 1.0f / spacing : 0.0f);
+            const uint32_t m = pow3(l);
+            out[base + kLatOffset + l] = (uint32_t)out.size() - base;
+            for (float v : X[l]) out.push_back(bits_of(v));
+            for (float v : Y[l]) out.push_back(bits_of(v));
+            for (float v : Z[l]) out.push_back(bits_of(v));
+            for (uint32_t i = 0; i < m; i++) {
+                uint32_t ones = 0, r = i;
+                for (uint32_t d = 0; d < l; d++) {
+                    if (r % 3 == 1) ones |= 1u << d;
+                    r /= 3;
+                }
+                out.push_back(ones);
+            }
+            for (const std::vector<float> *t : { &X[l], &Y[l], &Z[l] })
+                for (float v : *t) bound = std::fmax(bound, std::fabs((double)v));
+        }
+        put_f(base + 2, (float)(3.0 * bound + 3.0 * half[0]));
+        return base;
+    }
+};
+
 struct Compiler {
     const rm_node *nodes;
     uint32_t n_nodes;
+    bool use_lattice;
     HostProgram &out;
     std::string &error;
     uint32_t cursor = 0;
@@ -65,6 +215,38 @@ struct Compiler {
         out.n_prims++;
     }
 
+    // If the primitive children starting at `cursor` (at most `left` of them) begin with a
+    // complete Menger lattice of >= 2 levels, emits a LATTICE op for it and returns the
+    // number of children consumed; otherwise 0.
+    uint32_t try_lattice(uint32_t left, uint32_t fold) {
+        if (!use_lattice || fold != (FOLD_MAX | FOLD_NEG)) return 0;
+        // how many consecutive cubic crosses are there
+        uint32_t avail = 0;
+        while (avail < left && cursor + avail < n_nodes && nodes[cursor + avail].type == RM_CROSS &&
+               iso(nodes[cursor + avail]))
+            avail++;
+        uint32_t levels = 0;
+        while (levels < kLatticeMaxLevels && lattice_size(levels + 1) <= avail) levels++;
+        LatticeMatcher m{};
+        m.nodes = nodes + cursor;
+        for (; levels >= 2; levels--) {
+            // table words of this candidate must fit the per-workgroup LDS budget
+            uint32_t words = kLatHeaderWords;
+            for (uint32_t l = 0; l < levels; l++) words += 4 * pow3(l);
+            if (out.lattice.size() + words > kLatticeMaxWords) continue;
+            if (!m.match(levels)) continue;
+            const uint32_t count = (uint32_t)lattice_size(levels);
+            const uint32_t offset = m.emit(out.lattice);
+            const uint32_t first_row = out.n_prims;
+            for (uint32_t i = 0; i < count; i++) add_prim(nodes[cursor + i]);
+            out.ops.push_back(Op{ OP_LATTICE, levels | (fold << 8) | (offset << 12), first_row, count });
+            out.n_lattices++;
+            cursor += count;
+            return count;
+        }
+        return 0;
+    }
+
     // Compiles the children of the list at nodes[list_at]; cursor is on its first child.
     bool list_body(uint32_t list_at, uint32_t depth) {
         const uint32_t mode = nodes[list_at].mode;
@@ -86,12 +268,17 @@ struct Compiler {
                 continue;
             }
             if (n.type > RM_CROSS) return fail("node with an unknown type");
+            const bool first_child = (child == 0);
+            const uint32_t fold = fold_of(mode, first_child);
+            if (const uint32_t used = try_lattice(n_children - child, fold)) {
+                child += used;
+                continue;
+            }
             // a run: consecutive primitive children of the same kind; the first
             // child of the list gets a run of its own (it replaces the accumulator)
             const uint32_t kind = kind_of(n);
             const uint32_t first_row = out.n_prims;
             uint32_t count = 0;
-            const bool first_child = (child == 0);
             while (child < n_children && cursor < n_nodes && nodes[cursor].type != RM_LIST &&
                    nodes[cursor].type <= RM_CROSS && kind_of(nodes[cursor]) == kind) {
                 add_prim(nodes[cursor]);
@@ -100,7 +287,7 @@ struct Compiler {
                 count++;
                 if (first_child) break;
             }
-            out.ops.push_back(Op{ OP_RUN, kind | (fold_of(mode, first_child) << 8), first_row, count });
+            out.ops.push_back(Op{ OP_RUN, kind | (fold << 8), first_row, count });
         }
         return true;
     }
@@ -108,7 +295,7 @@ struct Compiler {
 
 }  // namespace
 
-bool compile_scene(const rm_node *nodes, uint32_t n_nodes, HostProgram &out, std::string &error) {
+bool compile_scene(const rm_node *nodes, uint32_t n_nodes, bool use_lattice, HostProgram &out, std::string &error) {
     out = HostProgram();
     if (!nodes || n_nodes == 0) {
         error = "empty node list (the root list is required)";
@@ -118,7 +305,7 @@ bool compile_scene(const rm_node *nodes, uint32_t n_nodes, HostProgram &out, std
         error = "the first node must be the root list";
         return false;
     }
-    Compiler c{ nodes, n_nodes, out, error };
+    Compiler c{ nodes, n_nodes, use_lattice, out, error };
     c.cursor = 1;
     if (!c.list_body(0, 0)) return false;
     if (c.cursor != n_nodes) {
@@ -132,6 +319,7 @@ bool compile_scene(const rm_node *nodes, uint32_t n_nodes, HostProgram &out, std
         out.pb.push_back(Float4{ 0, 0, 0, 0 });
         out.colors.push_back(Float4{ 0, 0, 0, 0 });
     }
+    if (out.lattice.empty()) out.lattice.push_back(0u);
     return true;
 }
 

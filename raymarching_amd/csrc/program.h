@@ -13,6 +13,8 @@ namespace rmdev {
 struct HostProgram {
     std::vector<Op> ops;
     std::vector<Float4> pa, pb, colors;
+    std::vector<uint32_t> lattice;   // Menger lattice blocks (device_scene.h)
+    uint32_t n_lattices = 0;
     uint32_t n_prims = 0;
     uint32_t n_lists = 0;
     uint32_t max_depth = 0;
@@ -22,6 +24,8 @@ struct HostProgram {
 };
 
 // Returns false and sets `error` if the node list is not a well-formed tree.
-bool compile_scene(const rm_node *nodes, uint32_t n_nodes, HostProgram &out, std::string &error);
+// use_lattice: recognise complete Menger lattices among the cross runs and emit LATTICE
+// operations for them (exact, sub-linear evaluation); false = every primitive is visited.
+bool compile_scene(const rm_node *nodes, uint32_t n_nodes, bool use_lattice, HostProgram &out, std::string &error);
 
 }  // namespace rmdev
