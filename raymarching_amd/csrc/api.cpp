@@ -70,7 +70,7 @@ struct rm_context {
     rmdev::HostProgram program;
     rmdev::SceneView scene{};
 
-    DeviceArray<rmdev::Op> d_ops;
+    DeviceArray<rmdev::Rec> d_recs;
     DeviceArray<rmdev::Float4> d_pa, d_pb, d_colors, d_lights, d_samples;
     DeviceArray<float> d_frame_f32;
     DeviceArray<unsigned char> d_frame_rgba8;
@@ -172,7 +172,7 @@ int rm_destroy(rm_context *ctx) {
     if (!ctx) return RM_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_ops.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
+    ctx->d_recs.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
     ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release();
@@ -202,7 +202,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     rmdev::HostProgram prog;
     if (!rmdev::compile_scene(nodes, n_nodes, ctx->evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_set_scene: " + why);
     RM_HIP(hipSetDevice(ctx->device));
-    RM_HIP(ctx->d_ops.reserve(prog.ops.size()));
+    RM_HIP(ctx->d_recs.reserve(prog.recs.size()));
     RM_HIP(ctx->d_pa.reserve(prog.pa.size()));
     RM_HIP(ctx->d_pb.reserve(prog.pb.size()));
     RM_HIP(ctx->d_colors.reserve(prog.colors.size()));
@@ -211,7 +211,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     std::vector<rmdev::Float4> lights(n_lights ? n_lights : 1, rmdev::Float4{ 0, 0, 0, 0 });
     for (uint32_t i = 0; i < n_lights; i++)
         lights[i] = rmdev::Float4{ lights_xyz[3 * i], lights_xyz[3 * i + 1], lights_xyz[3 * i + 2], 0.0f };
-    RM_HIP(hipMemcpyAsync(ctx->d_ops.ptr, prog.ops.data(), prog.ops.size() * sizeof(rmdev::Op), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_recs.ptr, prog.recs.data(), prog.recs.size() * sizeof(rmdev::Rec), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_pa.ptr, prog.pa.data(), prog.pa.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_pb.ptr, prog.pb.data(), prog.pb.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_colors.ptr, prog.colors.data(), prog.colors.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
@@ -220,7 +220,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
     ctx->program = std::move(prog);
     rmdev::SceneView &sv = ctx->scene;
-    sv.ops = ctx->d_ops.ptr; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
+    sv.recs = ctx->d_recs.ptr; sv.max_depth = ctx->program.max_depth; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
     sv.lattice = ctx->d_lattice.ptr;

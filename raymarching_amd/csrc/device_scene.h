@@ -1,25 +1,23 @@
-// device_scene.h -- the scene as the kernels see it: a flat "program" plus
-// structure-of-arrays primitive tables.  Shared by the host compiler
-// (program.cpp) and the kernels (kernels.hip).
+// device_scene.h -- the scene as the kernels see it: a flat stream of 32-byte
+// records plus structure-of-arrays tables for long homogeneous runs.  Shared by the
+// host compiler (program.cpp) and the kernels (kernels.hip).
 //
-// Body::List::SDF (/root/reference/source/body.cpp:66-111) folds its children
-// left to right into one running surface.  The tree is therefore compiled, in
-// depth-first order, into three kinds of operations whose list mode is already
-// resolved on the host:
+// Body::List::SDF (/root/reference/source/body.cpp:66-111) folds its children left to
+// right into one running surface.  The tree is compiled, in depth-first order, into
+// records whose list mode is already resolved on the host:
 //
-//   RUN  kind, fold, first, count   fold `count` consecutive primitives of one
-//                                   kind (table rows first..first+count-1)
-//                                   into the accumulator
-//   PUSH slot                       a nested list starts: park the accumulator
-//                                   in stack slot `slot`, start a new one
-//   POP  slot, fold                 the nested list ends: its accumulator is
-//                                   folded, as one child, into the parked one
-//   LATTICE levels, fold, first, count, table   a run of `count` cubic crosses that form a
-//                                   complete Menger lattice (see below), folded with max(s, -c)
+//   SPHERE / BOX / CROSS   one primitive (centre, half sizes or radius) and how it folds
+//   RUN                    `count` consecutive primitives of one kind and fold, rows
+//                          first..first+count-1 of the tables (long homogeneous runs only)
+//   LATTICE                a run of cubic crosses that form a complete Menger lattice
+//                          (see below), folded with max(s, -c)
+//   PUSH slot              a nested list starts: park the accumulator, start a new one
+//   POP  slot              the nested list ends: its accumulator is folded, as one child,
+//                          into the parked one
 //   END
 //
-// fold = {negate the child?, keep the larger (max) or the smaller (min)?,
-// is this the list's first child (then the child replaces the accumulator)?}:
+// fold = {negate the child?, keep the larger (max) or the smaller (min)?, is this the
+// list's first child (then the child replaces the accumulator)?}:
 //   UNION         first: s = c     then s = min(s,  c)
 //   COMPLEMENT    first: s = -c    then s = min(s, -c)
 //   INTERSECTION  first: s = c     then s = max(s,  c)
@@ -31,28 +29,35 @@
 
 namespace rmdev {
 
-enum OpCode : uint32_t { OP_END = 0, OP_RUN = 1, OP_PUSH = 2, OP_POP = 3, OP_LATTICE = 4 };
+enum RecCode : uint32_t {
+    REC_END = 0, REC_SPHERE = 1, REC_BOX = 2, REC_CROSS = 3, REC_PUSH = 4, REC_POP = 5, REC_RUN = 6, REC_LATTICE = 7
+};
 
 // Primitive kinds of a RUN.  The *_ISO kinds are boxes/crosses whose three edge
 // lengths are equal (everything the generators emit): one table row suffices.
 enum Kind : uint32_t { K_SPHERE = 1, K_BOX = 2, K_CROSS = 3, K_BOX_ISO = 4, K_CROSS_ISO = 5 };
 
-enum FoldBits : uint32_t { FOLD_NEG = 1u, FOLD_MAX = 2u, FOLD_FIRST = 4u };
+// fold bits as they sit in Rec::flags (above the 4-bit record code)
+enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u, FOLD_FIRST = 64u, FOLD_MASK = 112u };
 
-// 16 bytes, fetched with one scalar load.
-struct Op {
-    uint32_t code;   // OpCode
-    uint32_t arg;    // RUN: kind | fold << 8     PUSH: slot     POP: slot | fold << 8
-                     // LATTICE: levels | fold << 8 | (table offset in words) << 12
-    uint32_t first;  // RUN: first table row (= depth-first primitive index)
-    uint32_t count;  // RUN: number of primitives
+// 32 bytes, wave-uniform, fetched with one scalar load (s_load_dwordx8).
+//   primitive: a = (centre.x, centre.y, centre.z), h = (half.x | radius, half.y, half.z),
+//              prim = depth-first index of the primitive (its row in `colors`)
+//   RUN:       a = (first row, count, kind) as integers
+//   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
+//   PUSH, POP: a[0] = slot
+// half = size / 2 is exact in fp32, so precomputing it does not change a bit of
+// "abs(p - c) - size / 2" (body.cpp:42, :52).
+struct Rec {
+    uint32_t a[3];
+    uint32_t h[3];
+    uint32_t flags;   // RecCode | fold bits
+    uint32_t prim;
 };
 
 // Table row i describes the i-th primitive in depth-first order:
 //   pa[i] = (center.x, center.y, center.z, half.x or radius)
 //   pb[i] = (half.y, half.z, 0, 0)            (unused by spheres and *_ISO kinds)
-// half = size / 2, exact in fp32, so precomputing it does not change a bit of
-// "abs(p - c) - size / 2" (body.cpp:42, :52).
 struct Float4 { float x, y, z, w; };
 
 // ---- Menger lattice tables -------------------------------------------------
@@ -73,15 +78,17 @@ constexpr uint32_t kLatticeMaxWords = 12288;   // 48 KiB of LDS per workgroup at
 
 constexpr uint32_t kMaxDepth = 8;           // nested lists below the root
 constexpr uint32_t kNoPrim = 0xffffffffu;   // "colour of an empty list": black
+constexpr uint32_t kRunMin = 4;             // shorter homogeneous runs are emitted as single records
 
 struct SceneView {
-    const Op *ops;
+    const Rec *recs;
     const Float4 *pa;
     const Float4 *pb;
     const Float4 *colors;   // rgb per primitive
     const Float4 *lights;   // xyz per light
     const uint32_t *lattice;   // lattice blocks (staged into LDS by every workgroup)
     uint32_t lattice_words;
+    uint32_t max_depth;     // deepest PUSH slot + 1 (sizes the LDS parking area)
     uint32_t n_lights;
     uint32_t n_prims;
     float cam[16];          // column-major camera matrix

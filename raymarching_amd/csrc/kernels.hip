@@ -1,21 +1,22 @@
 // kernels.hip -- gfx950 kernels of the sphere-tracing render path.
 //
-// One SSAA sample per lane.  A lane does what scene::raymarch does for one
-// sample (/root/reference/source/scene.cpp:26-62): primary march, colour of the
-// hit, central-difference normal, one shadow march per light, clamped Lambert
-// sum.  A second kernel averages each pixel's kernel x kernel samples in the
-// reference's accumulation order (render.cpp:103-119) and quantises.
+// Two SSAA samples per lane (two horizontally adjacent sub-samples), 16 x 8 samples per
+// wave.  A lane does for each of its samples what scene::raymarch does
+// (/root/reference/source/scene.cpp:26-62): primary march, colour of the hit,
+// central-difference normal, one shadow march per light, clamped Lambert sum.  A second
+// kernel averages each pixel's kernel x kernel samples in the reference's accumulation
+// order (render.cpp:103-119) and quantises.
 //
-// Arithmetic contract: every fp32 operation below is a single correctly rounded
-// IEEE operation in the reference's order -- compiled with -ffp-contract=off
-// (no fused multiply-add) and hipcc's default correctly rounded sqrt / divide --
-// so the float framebuffer is bit-identical to the CPU path's (signs of zeros
-// and NaN payloads aside).
+// Arithmetic contract: every fp32 operation below is a single correctly rounded IEEE
+// operation in the reference's order -- compiled with -ffp-contract=off (no fused
+// multiply-add) and hipcc's default correctly rounded sqrt / divide -- so the float
+// framebuffer is bit-identical to the CPU path's (signs of zeros and NaN payloads aside).
 //
-// The scene is a flat program (device_scene.h).  All lanes of a wave walk the
-// same program at the same time, so operations and primitive rows are fetched
-// through wave-uniform addresses (scalar loads, operands in SGPRs); only the
-// sample position lives in vector registers.
+// The scene is a flat record stream (device_scene.h).  All lanes of a wave walk the same
+// stream at the same time, so records and table rows are fetched through wave-uniform
+// addresses (scalar loads, operands in SGPRs); only the sample positions live in vector
+// registers.  The scalar unit, one per CU, pays for every record; evaluating two points
+// per lane per walk halves that cost per point.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -23,6 +24,8 @@
 namespace rmdev {
 
 namespace {
+
+constexpr int kPts = 2;   // points per lane and scene walk in the render kernel
 
 struct V3 {
     float x, y, z;
@@ -39,59 +42,101 @@ __device__ __forceinline__ V3 normalize3(V3 a) {
     return a * inv;
 }
 
+// ---- LDS: lattice tables, then the parking area of nested lists -------------
+
+extern __shared__ uint32_t lds_words[];
+
+struct Lds {
+    const uint32_t *lattice;
+    uint32_t *park;   // [slot][sd | prim][point][thread]
+};
+
+__device__ __forceinline__ Lds stage_lds(const SceneView &sc) {
+    for (uint32_t i = threadIdx.x; i < sc.lattice_words; i += blockDim.x) lds_words[i] = sc.lattice[i];
+    __syncthreads();
+    return Lds{ lds_words, lds_words + sc.lattice_words };
+}
+
+inline uint32_t lds_bytes(const SceneView &sc) {
+    return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kPts * 256u) * 4u;
+}
+
 // ---- primitive distances (body.cpp:32-35, 41-45, 51-57) --------------------
 
-template <uint32_t KIND>
-__device__ __forceinline__ float prim_distance(const Float4 a, const Float4 b, float px, float py, float pz) {
-    if (KIND == K_SPHERE) {
-        const float dx = a.x - px, dy = a.y - py, dz = a.z - pz;
-        return __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - a.w;
-    }
-    const float hy = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.x;
-    const float hz = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.y;
-    const float dx = __builtin_fabsf(px - a.x) - a.w;
-    const float dy = __builtin_fabsf(py - a.y) - hy;
-    const float dz = __builtin_fabsf(pz - a.z) - hz;
-    if (KIND == K_BOX || KIND == K_BOX_ISO) {
-        return __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
-    }
+__device__ __forceinline__ float cross_value(float dx, float dy, float dz) {
     const float dmin = __builtin_fminf(__builtin_fminf(dx, dy), dz);
     const float dmax = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
     return dx + dy + dz - dmin - dmax;
 }
 
-// One RUN: fold `count` primitives of one kind into (acc, acc_prim).
-template <uint32_t KIND, bool NEG, bool MAX, bool TRACK>
-__device__ __forceinline__ void fold_run(const Float4 *__restrict__ pa, const Float4 *__restrict__ pb,
-                                         uint32_t first, uint32_t count, float px, float py, float pz,
-                                         float &acc, uint32_t &acc_prim) {
+template <uint32_t KIND>
+__device__ __forceinline__ float prim_distance(const Float4 a, const Float4 b, V3 p) {
+    if (KIND == K_SPHERE) {
+        const float dx = a.x - p.x, dy = a.y - p.y, dz = a.z - p.z;
+        return __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - a.w;
+    }
+    const float hy = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.x;
+    const float hz = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.y;
+    const float dx = __builtin_fabsf(p.x - a.x) - a.w;
+    const float dy = __builtin_fabsf(p.y - a.y) - hy;
+    const float dz = __builtin_fabsf(p.z - a.z) - hz;
+    if (KIND == K_BOX || KIND == K_BOX_ISO) return __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+    return cross_value(dx, dy, dz);
+}
+
+// Folds one child value per point into the accumulators (see device_scene.h).
+template <int NP, bool TRACK>
+__device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
+                                           float (&acc)[NP], uint32_t (&accp)[NP]) {
+    const bool neg = (flags & FOLD_NEG) != 0, mx = (flags & FOLD_MAX) != 0, first = (flags & FOLD_FIRST) != 0;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float c = neg ? -v[n] : v[n];
+        if (TRACK) {
+            // std::min / std::max on Surface: the accumulator survives ties
+            const bool take = first || (mx ? (acc[n] < c) : (c < acc[n]));
+            acc[n] = take ? c : acc[n];
+            accp[n] = take ? vprim[n] : accp[n];
+        } else {
+            const float f = mx ? __builtin_fmaxf(acc[n], c) : __builtin_fminf(acc[n], c);
+            acc[n] = first ? c : f;
+        }
+    }
+}
+
+// One RUN: `count` table rows of one kind, one fold.
+template <uint32_t KIND, bool NEG, bool MAX, int NP, bool TRACK>
+__device__ __forceinline__ void fold_run(const Float4 *__restrict__ pa, const Float4 *__restrict__ pb, uint32_t first,
+                                         uint32_t count, const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
     constexpr bool kNeedB = (KIND == K_BOX || KIND == K_CROSS);
 #pragma unroll 4
     for (uint32_t i = first; i < first + count; ++i) {
         const Float4 a = pa[i];
         Float4 b = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (kNeedB) b = pb[i];
-        float v = prim_distance<KIND>(a, b, px, py, pz);
-        if (NEG) v = -v;
-        if (TRACK) {
-            // std::min / std::max on Surface: the accumulator survives ties
-            const bool take = MAX ? (acc < v) : (v < acc);
-            acc = take ? v : acc;
-            acc_prim = take ? i : acc_prim;
-        } else {
-            acc = MAX ? __builtin_fmaxf(acc, v) : __builtin_fminf(acc, v);
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            float v = prim_distance<KIND>(a, b, p[n]);
+            if (NEG) v = -v;
+            if (TRACK) {
+                const bool take = MAX ? (acc[n] < v) : (v < acc[n]);
+                acc[n] = take ? v : acc[n];
+                accp[n] = take ? i : accp[n];
+            } else {
+                acc[n] = MAX ? __builtin_fmaxf(acc[n], v) : __builtin_fminf(acc[n], v);
+            }
         }
     }
 }
 
-template <uint32_t KIND, bool TRACK>
-__device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t fold, uint32_t first, uint32_t count,
-                                              float px, float py, float pz, float &acc, uint32_t &acc_prim) {
-    switch (fold & (FOLD_NEG | FOLD_MAX)) {
-    case 0: fold_run<KIND, false, false, TRACK>(sc.pa, sc.pb, first, count, px, py, pz, acc, acc_prim); break;
-    case FOLD_NEG: fold_run<KIND, true, false, TRACK>(sc.pa, sc.pb, first, count, px, py, pz, acc, acc_prim); break;
-    case FOLD_MAX: fold_run<KIND, false, true, TRACK>(sc.pa, sc.pb, first, count, px, py, pz, acc, acc_prim); break;
-    default: fold_run<KIND, true, true, TRACK>(sc.pa, sc.pb, first, count, px, py, pz, acc, acc_prim); break;
+template <uint32_t KIND, int NP, bool TRACK>
+__device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t flags, uint32_t first, uint32_t count,
+                                              const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
+    switch (flags & (FOLD_NEG | FOLD_MAX)) {
+    case 0: fold_run<KIND, false, false, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
+    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
+    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
+    default: fold_run<KIND, true, true, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
     }
 }
 
@@ -108,12 +153,6 @@ __device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t fold
 // with the exact reference formula, in the reference's operand order -- so the maximum, and
 // therefore every bit of the fold's result, equals the brute-force one.  Levels are visited
 // coarse to fine; a level whose half-width cannot beat `run` ends the walk (-c(p) <= half).
-__device__ __forceinline__ float cross_value(float dx, float dy, float dz) {
-    const float dmin = __builtin_fminf(__builtin_fminf(dx, dy), dz);
-    const float dmax = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
-    return dx + dy + dz - dmin - dmax;
-}
-
 __device__ __forceinline__ float axis_term(const uint32_t *tab, int i, float p, float h) {
     return __builtin_fabsf(p - __uint_as_float(tab[i])) - h;
 }
@@ -142,9 +181,9 @@ __device__ __forceinline__ void axis_range(const uint32_t *tab, int n, float p, 
 }
 
 template <bool TRACK, bool COUNT>
-__device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels, uint32_t first_row, float px, float py,
-                                             float pz, float &acc, uint32_t &acc_prim, uint32_t &n_evals) {
-    const float bound = __builtin_fabsf(px) + __builtin_fabsf(py) + __builtin_fabsf(pz) + __uint_as_float(w[2]);
+__device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels, uint32_t first_row, V3 p, float &acc,
+                                             uint32_t &acc_prim, uint32_t &n_evals) {
+    const float bound = __builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __uint_as_float(w[2]);
     const float eps = 2e-6f * bound;   // > 8x the worst rounding of dx + dy + dz - min - max at this magnitude
     float run = acc;
     int n = 1;
@@ -158,9 +197,9 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
         const uint32_t *Z = Y + n;
         const uint32_t *ONES = Z + n;
         int lox, hix, loy, hiy, loz, hiz;
-        axis_range(X, n, px, h, inv, tau, lox, hix);
-        axis_range(Y, n, py, h, inv, tau, loy, hiy);
-        axis_range(Z, n, pz, h, inv, tau, loz, hiz);
+        axis_range(X, n, p.x, h, inv, tau, lox, hix);
+        axis_range(Y, n, p.y, h, inv, tau, loy, hiy);
+        axis_range(Z, n, p.z, h, inv, tau, loz, hiz);
         if (COUNT) n_evals += 3;
         const bool bx = lox <= hix, by = loy <= hiy, bz = loz <= hiz;
         if (bx && by) {
@@ -168,9 +207,9 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int j = loy; j <= hiy; ++j) {
                     const uint32_t oi = ONES[i], oj = ONES[j];
                     if (oi & oj) continue;   // two zero offsets at one subdivision step: no such sub-cube
-                    const float dx = axis_term(X, i, px, h), dy = axis_term(Y, j, py, h);
+                    const float dx = axis_term(X, i, p.x, h), dy = axis_term(Y, j, p.y, h);
                     for (int k = 0; k < n; ++k) {
-                        const float v = -cross_value(dx, dy, axis_term(Z, k, pz, h));
+                        const float v = -cross_value(dx, dy, axis_term(Z, k, p.z, h));
                         run = (ONES[k] & (oi | oj)) ? run : __builtin_fmaxf(run, v);
                     }
                     if (COUNT) n_evals += n;
@@ -181,9 +220,9 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oi = ONES[i], ok = ONES[k];
                     if (oi & ok) continue;
-                    const float dx = axis_term(X, i, px, h), dz = axis_term(Z, k, pz, h);
+                    const float dx = axis_term(X, i, p.x, h), dz = axis_term(Z, k, p.z, h);
                     for (int j = 0; j < n; ++j) {
-                        const float v = -cross_value(dx, axis_term(Y, j, py, h), dz);
+                        const float v = -cross_value(dx, axis_term(Y, j, p.y, h), dz);
                         run = (ONES[j] & (oi | ok)) ? run : __builtin_fmaxf(run, v);
                     }
                     if (COUNT) n_evals += n;
@@ -194,9 +233,9 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oj = ONES[j], ok = ONES[k];
                     if (oj & ok) continue;
-                    const float dy = axis_term(Y, j, py, h), dz = axis_term(Z, k, pz, h);
+                    const float dy = axis_term(Y, j, p.y, h), dz = axis_term(Z, k, p.z, h);
                     for (int i = 0; i < n; ++i) {
-                        const float v = -cross_value(axis_term(X, i, px, h), dy, dz);
+                        const float v = -cross_value(axis_term(X, i, p.x, h), dy, dz);
                         run = (ONES[i] & (oj | ok)) ? run : __builtin_fmaxf(run, v);
                     }
                     if (COUNT) n_evals += n;
@@ -207,109 +246,99 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
     acc = run;
 }
 
-// Body::List::SDF for the whole tree (body.cpp:66-111) at one point per lane.
+// Body::List::SDF for the whole tree (body.cpp:66-111) at NP points per lane.
 // TRACK = false: distance only (march steps, gradient taps, shadow rays).
-// TRACK = true : also the depth-first index of the primitive whose colour the
-//                resulting Surface carries.
-template <bool TRACK, bool COUNT>
-__device__ __forceinline__ void scene_distance(const SceneView &sc, const uint32_t *lattice, float px, float py, float pz,
-                                               float &out_sd, uint32_t &out_prim, uint32_t &n_evals) {
+// TRACK = true : also the depth-first index of the primitive whose colour the resulting Surface
+//                carries.
+// n_evals[n] counts the primitive evaluations spent on point n (COUNT only).
+template <int NP, bool TRACK, bool COUNT>
+__device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
+                                               uint32_t (&out_prim)[NP], uint32_t (&n_evals)[NP]) {
     const float inf = __builtin_inff();
-    float acc = inf;              // an empty list is +inf / colour 0
-    uint32_t acc_prim = kNoPrim;
-    float parked[kMaxDepth];
-    uint32_t parked_prim[kMaxDepth];
+    float acc[NP];
+    uint32_t accp[NP];
 #pragma unroll
-    for (uint32_t d = 0; d < kMaxDepth; ++d) {
-        parked[d] = inf;
-        parked_prim[d] = kNoPrim;
+    for (int n = 0; n < NP; ++n) {
+        acc[n] = inf;   // an empty list is +inf / colour 0
+        accp[n] = kNoPrim;
     }
-    const Op *__restrict__ ops = sc.ops;
+    const Rec *__restrict__ recs = sc.recs;
     for (uint32_t pc = 0;; ++pc) {
-        const Op op = ops[pc];
-        if (op.code == OP_END) break;
-        if (op.code == OP_RUN) {
-            const uint32_t kind = op.arg & 0xffu, fold = op.arg >> 8;
-            if (fold & FOLD_FIRST) {
-                // the first child replaces the accumulator: start from the fold's identity
-                acc = (fold & FOLD_MAX) ? -inf : inf;
-                acc_prim = kNoPrim;
+        const Rec r = recs[pc];
+        const uint32_t code = r.flags & 15u;
+        if (code == REC_END) break;
+        if (code <= REC_CROSS) {
+            float v[NP];
+            uint32_t vp[NP];
+            const float cx = __uint_as_float(r.a[0]), cy = __uint_as_float(r.a[1]), cz = __uint_as_float(r.a[2]);
+            const float h0 = __uint_as_float(r.h[0]), h1 = __uint_as_float(r.h[1]), h2 = __uint_as_float(r.h[2]);
+            if (code == REC_SPHERE) {
+#pragma unroll
+                for (int n = 0; n < NP; ++n) {
+                    const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
+                    v[n] = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NP; ++n) {
+                    const float dx = __builtin_fabsf(p[n].x - cx) - h0;
+                    const float dy = __builtin_fabsf(p[n].y - cy) - h1;
+                    const float dz = __builtin_fabsf(p[n].z - cz) - h2;
+                    const float dmin = __builtin_fminf(__builtin_fminf(dx, dy), dz);
+                    const float dmax = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+                    v[n] = (code == REC_CROSS) ? (dx + dy + dz - dmin - dmax) : dmax;
+                }
             }
-            if (COUNT) n_evals += op.count;
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                vp[n] = r.prim;
+                if (COUNT) n_evals[n] += 1;
+            }
+            fold_value<NP, TRACK>(r.flags, v, vp, acc, accp);
+        } else if (code == REC_RUN) {
+            const uint32_t first = r.a[0], count = r.a[1], kind = r.a[2];
+            if (COUNT) {
+#pragma unroll
+                for (int n = 0; n < NP; ++n) n_evals[n] += count;
+            }
             switch (kind) {
-            case K_SPHERE: fold_run_kind<K_SPHERE, TRACK>(sc, fold, op.first, op.count, px, py, pz, acc, acc_prim); break;
-            case K_BOX: fold_run_kind<K_BOX, TRACK>(sc, fold, op.first, op.count, px, py, pz, acc, acc_prim); break;
-            case K_CROSS: fold_run_kind<K_CROSS, TRACK>(sc, fold, op.first, op.count, px, py, pz, acc, acc_prim); break;
-            case K_BOX_ISO: fold_run_kind<K_BOX_ISO, TRACK>(sc, fold, op.first, op.count, px, py, pz, acc, acc_prim); break;
-            default: fold_run_kind<K_CROSS_ISO, TRACK>(sc, fold, op.first, op.count, px, py, pz, acc, acc_prim); break;
+            case K_SPHERE: fold_run_kind<K_SPHERE, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
+            case K_BOX: fold_run_kind<K_BOX, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
+            case K_CROSS: fold_run_kind<K_CROSS, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
+            case K_BOX_ISO: fold_run_kind<K_BOX_ISO, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
+            default: fold_run_kind<K_CROSS_ISO, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
             }
-        } else if (op.code == OP_LATTICE) {
-            lattice_fold<TRACK, COUNT>(lattice + (op.arg >> 12), op.arg & 0xfu, op.first, px, py, pz, acc, acc_prim, n_evals);
-        } else if (op.code == OP_PUSH) {
-            const uint32_t slot = op.arg;
+        } else if (code == REC_LATTICE) {
 #pragma unroll
-            for (uint32_t d = 0; d < kMaxDepth; ++d) {
-                if (d == slot) {
-                    parked[d] = acc;
-                    parked_prim[d] = acc_prim;
-                }
-            }
-            acc = inf;
-            acc_prim = kNoPrim;
-        } else {  // OP_POP: the finished list is one child of the parked accumulator
-            const uint32_t slot = op.arg & 0xffu, fold = op.arg >> 8;
-            float v = (fold & FOLD_NEG) ? -acc : acc;
-            const uint32_t v_prim = acc_prim;
-            float up = inf;
-            uint32_t up_prim = kNoPrim;
+            for (int n = 0; n < NP; ++n)
+                lattice_fold<TRACK, COUNT>(lds.lattice + r.a[1], r.a[0], r.prim, p[n], acc[n], accp[n], n_evals[n]);
+        } else if (code == REC_PUSH) {
+            uint32_t *slot = lds.park + r.a[0] * (2u * kPts * 256u) + threadIdx.x;
 #pragma unroll
-            for (uint32_t d = 0; d < kMaxDepth; ++d) {
-                if (d == slot) {
-                    up = parked[d];
-                    up_prim = parked_prim[d];
-                }
+            for (int n = 0; n < NP; ++n) {
+                slot[n * 256] = __float_as_uint(acc[n]);
+                if (TRACK) slot[(kPts + n) * 256] = accp[n];
+                acc[n] = inf;
+                accp[n] = kNoPrim;
             }
-            if (fold & FOLD_FIRST) {
-                up = (fold & FOLD_MAX) ? -inf : inf;
-                up_prim = kNoPrim;
+        } else {   // REC_POP: the finished list is one child of the parked accumulator
+            const uint32_t *slot = lds.park + r.a[0] * (2u * kPts * 256u) + threadIdx.x;
+            float v[NP];
+            uint32_t vp[NP];
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                v[n] = acc[n];
+                vp[n] = accp[n];
+                acc[n] = __uint_as_float(slot[n * 256]);
+                if (TRACK) accp[n] = slot[(kPts + n) * 256];
             }
-            const bool take = (fold & FOLD_MAX) ? (up < v) : (v < up);
-            acc = take ? v : up;
-            acc_prim = take ? v_prim : up_prim;
+            fold_value<NP, TRACK>(r.flags, v, vp, acc, accp);
         }
     }
-    out_sd = acc;
-    out_prim = acc_prim;
-}
-
-template <bool COUNT>
-__device__ __forceinline__ float scene_sd(const SceneView &sc, const uint32_t *lattice, V3 p, uint32_t &n_evals) {
-    float sd;
-    uint32_t prim;
-    scene_distance<false, COUNT>(sc, lattice, p.x, p.y, p.z, sd, prim, n_evals);
-    return sd;
-}
-
-extern __shared__ uint32_t lds_lattice[];
-
-// Every workgroup keeps the lattice tables in LDS (a few KB; 0 words when the scene has none).
-__device__ __forceinline__ const uint32_t *stage_lattice(const SceneView &sc) {
-    for (uint32_t i = threadIdx.x; i < sc.lattice_words; i += blockDim.x) lds_lattice[i] = sc.lattice[i];
-    __syncthreads();
-    return lds_lattice;
-}
-
-// scene::surface (scene.cpp:34-42): advances p along ray; `at` is the point of
-// the last SDF evaluation (whose Surface the reference returns).
-template <bool COUNT>
-__device__ __forceinline__ void march(const SceneView &sc, const uint32_t *lattice, const FrameView &fr, V3 &p, V3 ray,
-                                      V3 &at, uint32_t &n_sdf, uint32_t &n_evals) {
-    for (int it = 0; it < fr.iterations; ++it) {
-        at = p;
-        const float sd = scene_sd<COUNT>(sc, lattice, p, n_evals);
-        if (COUNT) n_sdf++;
-        p = p + ray * sd;
-        if (sd < fr.surface_eps) break;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        out_sd[n] = acc[n];
+        out_prim[n] = accp[n];
     }
 }
 
@@ -320,7 +349,47 @@ __device__ __forceinline__ V3 camera_view(const float *m, V3 v, float w) {
 
 __device__ __forceinline__ float lerp1(float u, float v, float t) { return u + t * (v - u); }
 
-// Block = 16 x 16 sub-samples, each wave an 8 x 8 quadrant.
+struct LaneCounts {
+    uint32_t sdf, steps, rays, evals;
+};
+
+// scene::surface (scene.cpp:34-42) for the lane's two samples in lockstep: advances p[s]
+// along ray[s] while sample s is live; at[s] is the point of its last SDF evaluation (whose
+// Surface the reference returns).
+template <bool COUNT>
+__device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
+                                      const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], LaneCounts &cnt) {
+    bool done[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        done[s] = !live[s];
+        if (COUNT && live[s]) cnt.rays++;
+    }
+    for (int it = 0; it < fr.iterations; ++it) {
+        bool all_done = true;
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
+        if (all_done) break;
+        float sd[kPts];
+        uint32_t prim[kPts], evals[kPts] = {};
+        scene_distance<kPts, false, COUNT>(sc, lds, p, sd, prim, evals);
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) {
+            if (!done[s]) {
+                at[s] = p[s];
+                p[s] = p[s] + ray[s] * sd[s];
+                done[s] = sd[s] < fr.surface_eps;
+                if (COUNT) {
+                    cnt.sdf++;
+                    cnt.steps++;
+                    cnt.evals += evals[s];
+                }
+            }
+        }
+    }
+}
+
+// Block = 32 x 16 sub-samples; each wave a 16 x 8 tile, each lane two horizontally adjacent samples.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const FrameView fr, Float4 *__restrict__ samples,
                                                      WorkCounters *__restrict__ counters) {
@@ -328,104 +397,155 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const Fr
     if (COUNT) {
         if (threadIdx.x < 4) block_counts[threadIdx.x] = 0;
     }
-    const uint32_t *lattice = stage_lattice(sc);
+    const Lds lds = stage_lds(sc);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
-    const uint32_t sx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t sx0 = blockIdx.x * 32u + (wave & 1u) * 16u + (lane & 7u) * 2u;
     const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    uint32_t n_sdf = 0, n_steps = 0, n_rays = 0, n_evals = 0;
+    LaneCounts cnt = { 0, 0, 0, 0 };
 
-    if (sx < sw && sy < sh) {
-        const uint32_t pj = sx / k, i = sx - pj * k;    // pixel column, sub-sample column (outer loop index)
-        const uint32_t ly = sy / k, j = sy - ly * k;    // local pixel row, sub-sample row (inner loop index)
-        const uint32_t band = ly / fr.band_rows;
-        const uint32_t pi = (fr.first_band + band * fr.band_stride) * fr.band_rows + (ly - band * fr.band_rows);
-        V3 color = v3(0.0f, 0.0f, 0.0f);
-        if (pi < fr.height) {
-            // ---- render::pixel, render.cpp:82-111
-            const float AR = (float)fr.width / (float)fr.height;
-            const float w = sc.focal;
-            const float h = w / AR;
-            const float s1x = -w / 2, s1y = h / 2;
-            const float s2x = w / 2, s2y = -h / 2;
-            const float psx = 1.0f / (float)fr.width, psy = 1.0f / (float)fr.height;
-            const float uv1x = (float)pj * psx, uv1y = (float)pi * psy;
-            const float uv2x = (float)(pj + 1u) * psx, uv2y = (float)(pi + 1u) * psy;
-            const float p1x = lerp1(s1x, s2x, uv1x), p1y = lerp1(s1y, s2y, uv1y);
-            const float p2x = lerp1(s1x, s2x, uv2x), p2y = lerp1(s1y, s2y, uv2y);
-            const V3 origin = camera_view(sc.cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
-            const float uvx = (float)(i + 1u) / (float)k, uvy = (float)(j + 1u) / (float)k;
-            const float x = lerp1(p1x, p2x, uvx);
-            const float y = lerp1(p1y, p2y, uvy);
-            V3 ray = normalize3(v3(x, y, -1.0f));
-            ray = camera_view(sc.cam, ray, 0.0f);
+    // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
+    const float AR = (float)fr.width / (float)fr.height;
+    const float w = sc.focal;
+    const float h = w / AR;
+    const float s1x = -w / 2, s1y = h / 2;
+    const float s2x = w / 2, s2y = -h / 2;
+    const float psx = 1.0f / (float)fr.width, psy = 1.0f / (float)fr.height;
+    const V3 origin = camera_view(sc.cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
+    const uint32_t ly = sy / k, j = sy - ly * k;   // local pixel row, sub-sample row (inner loop index)
+    const uint32_t band = ly / fr.band_rows;
+    const uint32_t pi = (fr.first_band + band * fr.band_stride) * fr.band_rows + (ly - band * fr.band_rows);
+    const float uv1y = (float)pi * psy, uv2y = (float)(pi + 1u) * psy;
+    const float p1y = lerp1(s1y, s2y, uv1y), p2y = lerp1(s1y, s2y, uv2y);
+    const float uvy = (float)(j + 1u) / (float)k;
+    const float y = lerp1(p1y, p2y, uvy);
 
-            // ---- scene::raymarch, scene.cpp:26-32
-            V3 p = origin, at = origin;
-            uint32_t steps0 = n_sdf;
-            march<COUNT>(sc, lattice, fr, p, ray, at, n_sdf, n_evals);
-            if (COUNT) { n_steps += n_sdf - steps0; n_rays++; }
-            uint32_t prim = kNoPrim;
-            if (fr.iterations > 0) {
-                float sd_unused;
-                uint32_t evals_unused = 0;   // the colour pass repeats the last march evaluation: not extra work of the algorithm
-                scene_distance<true, false>(sc, lattice, at.x, at.y, at.z, sd_unused, prim, evals_unused);
-            }
-            // scene::grad, scene.cpp:70-89
-            const float hh = 1e-3f;
-            float g[3] = { 0.0f, 0.0f, 0.0f };
+    bool stored[kPts], live[kPts];
+    V3 cam_ray[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        const uint32_t sx = sx0 + (uint32_t)s;
+        stored[s] = sx < sw && sy < sh;
+        live[s] = stored[s] && pi < fr.height;
+        const uint32_t pj = sx / k, i = sx - pj * k;   // pixel column, sub-sample column (outer loop index)
+        const float uv1x = (float)pj * psx, uv2x = (float)(pj + 1u) * psx;
+        const float p1x = lerp1(s1x, s2x, uv1x), p2x = lerp1(s1x, s2x, uv2x);
+        const float uvx = (float)(i + 1u) / (float)k;
+        const float x = lerp1(p1x, p2x, uvx);
+        cam_ray[s] = camera_view(sc.cam, normalize3(v3(x, y, -1.0f)), 0.0f);
+    }
+
+    // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
+    // ray to light l (scene::lighting / scene::shadow, scene.cpp:45-62).  One march instance.
+    V3 hit[kPts], normal[kPts], p[kPts], ray[kPts], at[kPts];
+    float lighting[kPts];
+    uint32_t prim[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        hit[s] = origin;
+        normal[s] = v3(0.0f, 0.0f, 0.0f);
+        lighting[s] = 0.0f;
+        prim[s] = kNoPrim;
+    }
+    const float lift = fr.surface_eps + fr.offset_eps;
 #pragma unroll 1
-            for (int axis = 0; axis < 3; ++axis) {   // one evaluator instance for the six taps
+    for (uint32_t r = 0; r <= sc.n_lights; ++r) {
+        V3 light = v3(0.0f, 0.0f, 0.0f);
+        if (r == 0) {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                p[s] = origin;
+                ray[s] = cam_ray[s];
+            }
+        } else {
+            const Float4 lp = sc.lights[r - 1];
+            light = v3(lp.x, lp.y, lp.z);
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                ray[s] = normalize3(light - hit[s]);
+                p[s] = hit[s] + normal[s] * lift;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) at[s] = p[s];
+        march<COUNT>(sc, lds, fr, p, ray, at, live, cnt);
+        if (r == 0) {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) hit[s] = p[s];
+            // the Surface scene::surface returned: colour of the last evaluation
+            if (fr.iterations > 0) {
+                float sd_unused[kPts];
+                uint32_t evals_unused[kPts] = {};
+                scene_distance<kPts, true, false>(sc, lds, at, sd_unused, prim, evals_unused);
+            }
+            // scene::grad, scene.cpp:70-89: six taps, one evaluator instance
+            const float hh = 1e-3f;
+            float g[kPts][3] = {};
+#pragma unroll 1
+            for (int axis = 0; axis < 3; ++axis) {
                 const V3 e = v3(axis == 0 ? hh : 0.0f, axis == 1 ? hh : 0.0f, axis == 2 ? hh : 0.0f);
-                float tap[2];
+                float plus[kPts] = {};
 #pragma unroll 1
                 for (int side = 0; side < 2; ++side) {
-                    const V3 q = side == 0 ? v3(p.x + e.x, p.y + e.y, p.z + e.z) : v3(p.x - e.x, p.y - e.y, p.z - e.z);
-                    const float sd = scene_sd<COUNT>(sc, lattice, q, n_evals);
-                    tap[0] = side == 0 ? sd : tap[0];
-                    tap[1] = sd;
+                    V3 q[kPts];
+#pragma unroll
+                    for (int s = 0; s < kPts; ++s)
+                        q[s] = side == 0 ? v3(hit[s].x + e.x, hit[s].y + e.y, hit[s].z + e.z)
+                                         : v3(hit[s].x - e.x, hit[s].y - e.y, hit[s].z - e.z);
+                    float sd[kPts];
+                    uint32_t prim_unused[kPts], evals[kPts] = {};
+                    scene_distance<kPts, false, COUNT>(sc, lds, q, sd, prim_unused, evals);
+#pragma unroll
+                    for (int s = 0; s < kPts; ++s) {
+                        if (COUNT && live[s]) {
+                            cnt.sdf++;
+                            cnt.evals += evals[s];
+                        }
+                        const float diff = plus[s] - sd[s];
+                        plus[s] = side == 0 ? sd[s] : plus[s];
+                        if (side == 1) {
+                            g[s][0] = axis == 0 ? diff : g[s][0];
+                            g[s][1] = axis == 1 ? diff : g[s][1];
+                            g[s][2] = axis == 2 ? diff : g[s][2];
+                        }
+                    }
                 }
-                const float diff = tap[0] - tap[1];
-                g[0] = axis == 0 ? diff : g[0];
-                g[1] = axis == 1 ? diff : g[1];
-                g[2] = axis == 2 ? diff : g[2];
             }
-            if (COUNT) n_sdf += 6;
             const float two_h = 2 * hh;
-            const V3 normal = normalize3(v3(g[0] / two_h, g[1] / two_h, g[2] / two_h));
-
-            // scene::lighting + scene::shadow, scene.cpp:45-62
-            float lighting = 0.0f;
-            const float lift = fr.surface_eps + fr.offset_eps;
-            for (uint32_t l = 0; l < sc.n_lights; ++l) {
-                const Float4 lp = sc.lights[l];
-                const V3 light = v3(lp.x, lp.y, lp.z);
-                const V3 to_light = normalize3(light - p);
-                V3 q = p + normal * lift;
-                V3 q_at = q;
-                steps0 = n_sdf;
-                march<COUNT>(sc, lattice, fr, q, to_light, q_at, n_sdf, n_evals);
-                if (COUNT) { n_steps += n_sdf - steps0; n_rays++; }
-                const bool shadowed = dot3(light - q, to_light) > 0;
-                if (!shadowed) lighting += dot3(normal, to_light);
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) normal[s] = normalize3(v3(g[s][0] / two_h, g[s][1] / two_h, g[s][2] / two_h));
+        } else {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                const bool shadowed = dot3(light - p[s], ray[s]) > 0;
+                if (!shadowed) lighting[s] += dot3(normal[s], ray[s]);
             }
-            lighting = __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting), 1.0f);
+        }
+    }
+
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        if (!stored[s]) continue;
+        V3 color = v3(0.0f, 0.0f, 0.0f);
+        if (live[s]) {
+            const float light = __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f);
             V3 base = v3(0.0f, 0.0f, 0.0f);
-            if (prim != kNoPrim) {
-                const Float4 c = sc.colors[prim];
+            if (prim[s] != kNoPrim) {
+                const Float4 c = sc.colors[prim[s]];
                 base = v3(c.x, c.y, c.z);
             }
-            color = v3(lighting * base.x, lighting * base.y, lighting * base.z);
+            color = v3(light * base.x, light * base.y, light * base.z);
         }
-        samples[(size_t)sy * sw + sx] = Float4{ color.x, color.y, color.z, 0.0f };
+        samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
     }
+
     if (COUNT) {
-        atomicAdd(&block_counts[0], (unsigned long long)n_sdf);
-        atomicAdd(&block_counts[1], (unsigned long long)n_steps);
-        atomicAdd(&block_counts[2], (unsigned long long)n_rays);
-        atomicAdd(&block_counts[3], (unsigned long long)n_evals);
+        atomicAdd(&block_counts[0], (unsigned long long)cnt.sdf);
+        atomicAdd(&block_counts[1], (unsigned long long)cnt.steps);
+        atomicAdd(&block_counts[2], (unsigned long long)cnt.rays);
+        atomicAdd(&block_counts[3], (unsigned long long)cnt.evals);
         __syncthreads();
         if (threadIdx.x == 0) {
             atomicAdd(&counters->sdf_calls, block_counts[0]);
@@ -474,14 +594,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
 
 __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const float *__restrict__ xyz, uint32_t n,
                                                         float *__restrict__ sd, uint32_t *__restrict__ prim) {
-    const uint32_t *lattice = stage_lattice(sc);
+    const Lds lds = stage_lds(sc);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    float d;
-    uint32_t p, evals = 0;
-    scene_distance<true, false>(sc, lattice, xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], d, p, evals);
-    sd[t] = d;
-    prim[t] = p;
+    const uint32_t tt = t < n ? t : n - 1;   // every lane walks the scene (nested lists park through LDS)
+    const V3 p[1] = { v3(xyz[3 * tt], xyz[3 * tt + 1], xyz[3 * tt + 2]) };
+    float d[1];
+    uint32_t pr[1], evals[1] = {};
+    scene_distance<1, true, false>(sc, lds, p, d, pr, evals);
+    if (t < n) {
+        sd[t] = d[0];
+        prim[t] = pr[0];
+    }
 }
 
 }  // namespace
@@ -495,11 +618,11 @@ hipError_t launch_trace(const SceneView &sc, const FrameView &fr, Float4 *sample
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0) return hipSuccess;
-    const dim3 grid((sw + 15u) / 16u, (sh + 15u) / 16u, 1u);
+    const dim3 grid((sw + 31u) / 32u, (sh + 15u) / 16u, 1u);
     if (counters) {
-        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(256), sc.lattice_words * 4u, stream, sc, fr, samples, counters);
+        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(256), lds_bytes(sc), stream, sc, fr, samples, counters);
     } else {
-        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(256), sc.lattice_words * 4u, stream, sc, fr, samples, counters);
+        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(256), lds_bytes(sc), stream, sc, fr, samples, counters);
     }
     return hipGetLastError();
 }
@@ -516,7 +639,7 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out
 hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd, uint32_t *prim,
                            hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_sdf_kernel, dim3((n + 255u) / 256u), dim3(256), sc.lattice_words * 4u, stream, sc, xyz, n, sd, prim);
+    hipLaunchKernelGGL(eval_sdf_kernel, dim3((n + 255u) / 256u), dim3(256), lds_bytes(sc), stream, sc, xyz, n, sd, prim);
     return hipGetLastError();
 }
 

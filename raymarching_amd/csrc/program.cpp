@@ -197,7 +197,8 @@ struct Compiler {
         }
     }
 
-    void add_prim(const rm_node &n) {
+    // appends the table row of a primitive and returns its index
+    uint32_t add_prim(const rm_node &n) {
         Float4 a = { n.center[0], n.center[1], n.center[2], 0.0f };
         Float4 b = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (n.type == RM_SPHERE) {
@@ -212,11 +213,23 @@ struct Compiler {
         out.pa.push_back(a);
         out.pb.push_back(b);
         out.colors.push_back(Float4{ n.color[0], n.color[1], n.color[2], 0.0f });
-        out.n_prims++;
+        return out.n_prims++;
+    }
+
+    void emit_single(const rm_node &n, uint32_t fold) {
+        const uint32_t row = add_prim(n);
+        Rec r = {};
+        r.a[0] = bits_of(n.center[0]); r.a[1] = bits_of(n.center[1]); r.a[2] = bits_of(n.center[2]);
+        r.h[0] = bits_of(out.pa[row].w);
+        r.h[1] = n.type == RM_SPHERE ? 0u : bits_of(out.pb[row].x);
+        r.h[2] = n.type == RM_SPHERE ? 0u : bits_of(out.pb[row].y);
+        r.flags = (n.type == RM_SPHERE ? REC_SPHERE : n.type == RM_BOX ? REC_BOX : REC_CROSS) | fold;
+        r.prim = row;
+        out.recs.push_back(r);
     }
 
     // If the primitive children starting at `cursor` (at most `left` of them) begin with a
-    // complete Menger lattice of >= 2 levels, emits a LATTICE op for it and returns the
+    // complete Menger lattice of >= 2 levels, emits a LATTICE record for it and returns the
     // number of children consumed; otherwise 0.
     uint32_t try_lattice(uint32_t left, uint32_t fold) {
         if (!use_lattice || fold != (FOLD_MAX | FOLD_NEG)) return 0;
@@ -239,7 +252,11 @@ struct Compiler {
             const uint32_t offset = m.emit(out.lattice);
             const uint32_t first_row = out.n_prims;
             for (uint32_t i = 0; i < count; i++) add_prim(nodes[cursor + i]);
-            out.ops.push_back(Op{ OP_LATTICE, levels | (fold << 8) | (offset << 12), first_row, count });
+            Rec r = {};
+            r.a[0] = levels; r.a[1] = offset; r.a[2] = count;
+            r.flags = REC_LATTICE | fold;
+            r.prim = first_row;
+            out.recs.push_back(r);
             out.n_lattices++;
             cursor += count;
             return count;
@@ -253,7 +270,6 @@ struct Compiler {
         const uint32_t n_children = nodes[list_at].child_count;
         if (mode > RM_DIFFERENCE) return fail("list node with an unknown mode");
         out.n_lists++;
-        if (depth > out.max_depth) out.max_depth = depth;
         uint32_t child = 0;
         while (child < n_children) {
             if (cursor >= n_nodes) return fail("node list ends inside a list (child_count too large)");
@@ -261,33 +277,48 @@ struct Compiler {
             if (n.type == RM_LIST) {
                 if (depth >= kMaxDepth) return fail("lists nested deeper than 8 levels");
                 const uint32_t at = cursor++;
-                out.ops.push_back(Op{ OP_PUSH, depth, 0, 0 });
+                Rec push = {};
+                push.a[0] = depth;
+                push.flags = REC_PUSH;
+                out.recs.push_back(push);
+                if (depth + 1 > out.max_depth) out.max_depth = depth + 1;
                 if (!list_body(at, depth + 1)) return false;
-                out.ops.push_back(Op{ OP_POP, depth | (fold_of(mode, child == 0) << 8), 0, 0 });
+                Rec pop = {};
+                pop.a[0] = depth;
+                pop.flags = REC_POP | fold_of(mode, child == 0);
+                out.recs.push_back(pop);
                 child++;
                 continue;
             }
             if (n.type > RM_CROSS) return fail("node with an unknown type");
-            const bool first_child = (child == 0);
-            const uint32_t fold = fold_of(mode, first_child);
+            const uint32_t fold = fold_of(mode, child == 0);
+            if (child == 0) {   // the first child replaces the accumulator: always a record of its own
+                emit_single(n, fold);
+                cursor++;
+                child++;
+                continue;
+            }
             if (const uint32_t used = try_lattice(n_children - child, fold)) {
                 child += used;
                 continue;
             }
-            // a run: consecutive primitive children of the same kind; the first
-            // child of the list gets a run of its own (it replaces the accumulator)
+            // consecutive primitive children of the same kind: a RUN over the tables if long enough
             const uint32_t kind = kind_of(n);
-            const uint32_t first_row = out.n_prims;
-            uint32_t count = 0;
-            while (child < n_children && cursor < n_nodes && nodes[cursor].type != RM_LIST &&
-                   nodes[cursor].type <= RM_CROSS && kind_of(nodes[cursor]) == kind) {
-                add_prim(nodes[cursor]);
-                cursor++;
-                child++;
-                count++;
-                if (first_child) break;
+            uint32_t len = 0;
+            while (child + len < n_children && cursor + len < n_nodes && nodes[cursor + len].type != RM_LIST &&
+                   nodes[cursor + len].type <= RM_CROSS && kind_of(nodes[cursor + len]) == kind)
+                len++;
+            if (len >= kRunMin) {
+                Rec r = {};
+                r.a[0] = out.n_prims; r.a[1] = len; r.a[2] = kind;
+                r.flags = REC_RUN | fold;
+                out.recs.push_back(r);
+                for (uint32_t i = 0; i < len; i++) add_prim(nodes[cursor + i]);
+            } else {
+                for (uint32_t i = 0; i < len; i++) emit_single(nodes[cursor + i], fold);
             }
-            out.ops.push_back(Op{ OP_RUN, kind | (fold << 8), first_row, count });
+            cursor += len;
+            child += len;
         }
         return true;
     }
@@ -312,7 +343,7 @@ bool compile_scene(const rm_node *nodes, uint32_t n_nodes, bool use_lattice, Hos
         error = "nodes left over after the root list's children";
         return false;
     }
-    out.ops.push_back(Op{ OP_END, 0, 0, 0 });
+    out.recs.push_back(Rec{});   // REC_END
     // keep the tables non-empty so device pointers are always valid
     if (out.pa.empty()) {
         out.pa.push_back(Float4{ 0, 0, 0, 0 });

@@ -11,7 +11,7 @@
 namespace rmdev {
 
 struct HostProgram {
-    std::vector<Op> ops;
+    std::vector<Rec> recs;
     std::vector<Float4> pa, pb, colors;
     std::vector<uint32_t> lattice;   // Menger lattice blocks (device_scene.h)
     uint32_t n_lattices = 0;
