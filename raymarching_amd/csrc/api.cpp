@@ -113,7 +113,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
+    RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->program.run_prims >= 64, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -220,7 +220,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
     ctx->program = std::move(prog);
     rmdev::SceneView &sv = ctx->scene;
-    sv.recs = ctx->d_recs.ptr; sv.max_depth = ctx->program.max_depth; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
+    sv.recs = ctx->d_recs.ptr; sv.n_recs = static_cast<uint32_t>(ctx->program.recs.size()) - 1u; sv.max_depth = ctx->program.max_depth; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
     sv.lattice = ctx->d_lattice.ptr;

@@ -88,6 +88,7 @@ struct SceneView {
     const Float4 *lights;   // xyz per light
     const uint32_t *lattice;   // lattice blocks (staged into LDS by every workgroup)
     uint32_t lattice_words;
+    uint32_t n_recs;        // records before the END record
     uint32_t max_depth;     // deepest PUSH slot + 1 (sizes the LDS parking area)
     uint32_t n_lights;
     uint32_t n_prims;

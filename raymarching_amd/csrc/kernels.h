@@ -13,8 +13,9 @@ size_t sample_texels(const FrameView &fr);
 
 // Traces every SSAA sample of the launch's row bands (primary march, colour,
 // normal, one shadow ray per light, shading) into `samples`.
-// counters may be null (no counting).
-hipError_t launch_trace(const SceneView &sc, const FrameView &fr, Float4 *samples,
+// counters may be null (no counting).  wide_runs selects the one-sample-per-lane variant, for
+// scenes whose cost lies in long primitive runs.
+hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Float4 *samples,
                         WorkCounters *counters, hipStream_t stream);
 
 // Averages the kernel x kernel samples of each pixel in the reference's

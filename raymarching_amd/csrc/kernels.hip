@@ -25,11 +25,19 @@ namespace rmdev {
 
 namespace {
 
-constexpr int kPts = 2;   // points per lane and scene walk in the render kernel
+constexpr int kMaxPts = 2;   // most points per lane and scene walk (sizes the LDS parking area)
 
 struct V3 {
     float x, y, z;
 };
+
+typedef uint32_t RecWords __attribute__((ext_vector_type(8)));   // one Rec as a single 32-byte scalar load
+
+// Scene tables are never written while a kernel runs: reading them through the constant address
+// space keeps their wave-uniform loads on the scalar unit whatever else the kernel does.
+typedef const __attribute__((address_space(4))) RecWords *ConstRecs;
+typedef float RowWords __attribute__((ext_vector_type(4)));     // one Float4 table row
+typedef const __attribute__((address_space(4))) RowWords *ConstRows;
 
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -58,7 +66,7 @@ __device__ __forceinline__ Lds stage_lds(const SceneView &sc) {
 }
 
 inline uint32_t lds_bytes(const SceneView &sc) {
-    return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kPts * 256u) * 4u;
+    return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kMaxPts * 256u) * 4u;
 }
 
 // ---- primitive distances (body.cpp:32-35, 41-45, 51-57) --------------------
@@ -106,14 +114,19 @@ __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP],
 
 // One RUN: `count` table rows of one kind, one fold.
 template <uint32_t KIND, bool NEG, bool MAX, int NP, bool TRACK>
-__device__ __forceinline__ void fold_run(const Float4 *__restrict__ pa, const Float4 *__restrict__ pb, uint32_t first,
+__device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, uint32_t first,
                                          uint32_t count, const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
     constexpr bool kNeedB = (KIND == K_BOX || KIND == K_CROSS);
 #pragma unroll 4
     for (uint32_t i = first; i < first + count; ++i) {
-        const Float4 a = pa[i];
+        const RowWords ra = pa[i];
+        const Float4 a = { ra[0], ra[1], ra[2], ra[3] };
         Float4 b = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (kNeedB) b = pb[i];
+        if (kNeedB) {
+            const RowWords rb = pb[i];
+            b.x = rb[0];
+            b.y = rb[1];
+        }
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
             float v = prim_distance<KIND>(a, b, p[n]);
@@ -133,10 +146,10 @@ template <uint32_t KIND, int NP, bool TRACK>
 __device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t flags, uint32_t first, uint32_t count,
                                               const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
     switch (flags & (FOLD_NEG | FOLD_MAX)) {
-    case 0: fold_run<KIND, false, false, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
-    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
-    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
-    default: fold_run<KIND, true, true, NP, TRACK>(sc.pa, sc.pb, first, count, p, acc, accp); break;
+    case 0: fold_run<KIND, false, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
+    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
+    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
+    default: fold_run<KIND, true, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
     }
 }
 
@@ -262,11 +275,22 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
         acc[n] = inf;   // an empty list is +inf / colour 0
         accp[n] = kNoPrim;
     }
-    const Rec *__restrict__ recs = sc.recs;
-    for (uint32_t pc = 0;; ++pc) {
-        const Rec r = recs[pc];
+    // Records are fetched one ahead: the scalar load of record pc + 1 is in flight while record pc
+    // is evaluated (the stream ends with an END record, so pc + 1 is always readable).
+    const ConstRecs recs = (ConstRecs)(sc.recs);
+    RecWords next = recs[0];
+    for (uint32_t pc = 0; pc < sc.n_recs; ++pc) {
+        const RecWords cur = next;
+        // scalar loads return out of order, so a wait cannot single out the older load: retire
+        // record pc first (lgkmcnt(0)), then put record pc + 1 in flight behind it
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        next = recs[pc + 1];
+        Rec r;
+        r.a[0] = cur[0]; r.a[1] = cur[1]; r.a[2] = cur[2];
+        r.h[0] = cur[3]; r.h[1] = cur[4]; r.h[2] = cur[5];
+        r.flags = cur[6];
+        r.prim = cur[7];
         const uint32_t code = r.flags & 15u;
-        if (code == REC_END) break;
         if (code <= REC_CROSS) {
             float v[NP];
             uint32_t vp[NP];
@@ -313,16 +337,16 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
             for (int n = 0; n < NP; ++n)
                 lattice_fold<TRACK, COUNT>(lds.lattice + r.a[1], r.a[0], r.prim, p[n], acc[n], accp[n], n_evals[n]);
         } else if (code == REC_PUSH) {
-            uint32_t *slot = lds.park + r.a[0] * (2u * kPts * 256u) + threadIdx.x;
+            uint32_t *slot = lds.park + r.a[0] * (2u * kMaxPts * 256u) + threadIdx.x;
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
                 slot[n * 256] = __float_as_uint(acc[n]);
-                if (TRACK) slot[(kPts + n) * 256] = accp[n];
+                if (TRACK) slot[(kMaxPts + n) * 256] = accp[n];
                 acc[n] = inf;
                 accp[n] = kNoPrim;
             }
         } else {   // REC_POP: the finished list is one child of the parked accumulator
-            const uint32_t *slot = lds.park + r.a[0] * (2u * kPts * 256u) + threadIdx.x;
+            const uint32_t *slot = lds.park + r.a[0] * (2u * kMaxPts * 256u) + threadIdx.x;
             float v[NP];
             uint32_t vp[NP];
 #pragma unroll
@@ -330,7 +354,7 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
                 v[n] = acc[n];
                 vp[n] = accp[n];
                 acc[n] = __uint_as_float(slot[n * 256]);
-                if (TRACK) accp[n] = slot[(kPts + n) * 256];
+                if (TRACK) accp[n] = slot[(kMaxPts + n) * 256];
             }
             fold_value<NP, TRACK>(r.flags, v, vp, acc, accp);
         }
@@ -356,7 +380,7 @@ struct LaneCounts {
 // scene::surface (scene.cpp:34-42) for the lane's two samples in lockstep: advances p[s]
 // along ray[s] while sample s is live; at[s] is the point of its last SDF evaluation (whose
 // Surface the reference returns).
-template <bool COUNT>
+template <int kPts, bool COUNT>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], LaneCounts &cnt) {
     bool done[kPts];
@@ -389,9 +413,14 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     }
 }
 
-// Block = 32 x 16 sub-samples; each wave a 16 x 8 tile, each lane two horizontally adjacent samples.
-template <bool COUNT>
-__global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const FrameView fr, Float4 *__restrict__ samples,
+// kPts = 2: block = 32 x 16 sub-samples, each wave a 16 x 8 tile, each lane two horizontally
+// adjacent samples that march in lockstep -- halves the scalar-unit cost per sample, which bounds
+// scenes of few records; a sample that finishes early idles until its partner is done.
+// kPts = 1: block = 16 x 16, wave = 8 x 8, one sample per lane -- for scenes whose cost is in long
+// primitive runs (vector-ALU bound), where idling would cost more than the scalar unit saves.
+// MIN_WAVES: waves per SIMD the register allocation must allow.
+template <int kPts, int MIN_WAVES, bool COUNT>
+__global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView sc, const FrameView fr, Float4 *__restrict__ samples,
                                                      WorkCounters *__restrict__ counters) {
     __shared__ unsigned long long block_counts[4];
     if (COUNT) {
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const Fr
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
-    const uint32_t sx0 = blockIdx.x * 32u + (wave & 1u) * 16u + (lane & 7u) * 2u;
+    const uint32_t sx0 = blockIdx.x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
     const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
     LaneCounts cnt = { 0, 0, 0, 0 };
 
@@ -460,8 +489,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const Fr
                 ray[s] = cam_ray[s];
             }
         } else {
-            const Float4 lp = sc.lights[r - 1];
-            light = v3(lp.x, lp.y, lp.z);
+            const RowWords lp = ((ConstRows)sc.lights)[r - 1];
+            light = v3(lp[0], lp[1], lp[2]);
 #pragma unroll
             for (int s = 0; s < kPts; ++s) {
                 ray[s] = normalize3(light - hit[s]);
@@ -470,7 +499,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const SceneView sc, const Fr
         }
 #pragma unroll
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
-        march<COUNT>(sc, lds, fr, p, ray, at, live, cnt);
+        march<kPts, COUNT>(sc, lds, fr, p, ray, at, live, cnt);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
@@ -613,16 +642,20 @@ size_t sample_texels(const FrameView &fr) {
     return (size_t)fr.band_count * fr.band_rows * fr.kernel * (size_t)fr.width * fr.kernel;
 }
 
-hipError_t launch_trace(const SceneView &sc, const FrameView &fr, Float4 *samples, WorkCounters *counters,
+hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Float4 *samples, WorkCounters *counters,
                         hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0) return hipSuccess;
-    const dim3 grid((sw + 31u) / 32u, (sh + 15u) / 16u, 1u);
-    if (counters) {
-        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(256), lds_bytes(sc), stream, sc, fr, samples, counters);
+    const uint32_t pts = wide_runs ? 1u : 2u;
+    const dim3 grid((sw + 16u * pts - 1u) / (16u * pts), (sh + 15u) / 16u, 1u);
+    const uint32_t lds = lds_bytes(sc);
+    if (wide_runs) {
+        if (counters) hipLaunchKernelGGL((trace_kernel<1, 4, true>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
+        else hipLaunchKernelGGL((trace_kernel<1, 4, false>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
     } else {
-        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(256), lds_bytes(sc), stream, sc, fr, samples, counters);
+        if (counters) hipLaunchKernelGGL((trace_kernel<2, 8, true>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
+        else hipLaunchKernelGGL((trace_kernel<2, 8, false>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
     }
     return hipGetLastError();
 }

@@ -313,6 +313,7 @@ struct Compiler {
                 r.a[0] = out.n_prims; r.a[1] = len; r.a[2] = kind;
                 r.flags = REC_RUN | fold;
                 out.recs.push_back(r);
+                out.run_prims += len;
                 for (uint32_t i = 0; i < len; i++) add_prim(nodes[cursor + i]);
             } else {
                 for (uint32_t i = 0; i < len; i++) emit_single(nodes[cursor + i], fold);

@@ -16,6 +16,7 @@ struct HostProgram {
     std::vector<uint32_t> lattice;   // Menger lattice blocks (device_scene.h)
     uint32_t n_lattices = 0;
     uint32_t n_prims = 0;
+    uint32_t run_prims = 0;          // primitives evaluated through RUN records (table rows)
     uint32_t n_lists = 0;
     uint32_t max_depth = 0;
     // algorithmic cost of one scene SDF evaluation: 11 per sphere, 9 per box,
