@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the sphere-tracing hot path: Mrays/s (primary + shadow rays) and frame time.
 
-    python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd]
+    python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd|closeup6|synthetic]
+                    [--evaluator lattice|exhaustive]
 
 A step is one frame of the workload.  At N > 1 (one process per GPU, launched by
 torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
@@ -10,8 +11,14 @@ renders its bands into device memory and the RGBA8 bands are gathered to rank 0 
 is "strong".  Rank 0 prints ONE JSON line.
 
     value         = frames * W*H*k*k*(1+L) rays / wall time (max over ranks), in Mrays/s
-    roofline      = algorithmic FLOPs of the trace kernel (counted scene-SDF calls x FLOPs per
-                    call + 7 per march step) / its HIP-event duration, against the fp32 vector peak
+    roofline      = FLOPs the trace kernel EXECUTED for the frame (counted primitive evaluations x
+                    FLOPs per primitive + 7 per march step) / its HIP-event duration, against the
+                    fp32 vector peak.  With the default lattice evaluator most primitives are never
+                    visited; `brute_force_equivalent` gives the reference algorithm's FLOPs (counted
+                    scene-SDF calls x FLOPs of one exhaustive call) over the same time, a speed-up
+                    figure, not a roofline fraction.
+    roofline_exhaustive = the same kernel walking every primitive (evaluator "exhaustive"), timed in
+                    the same run on a few frames: executed == algorithmic FLOPs there.
     cpu_baseline  = the CPU oracle (a port of the reference's render::OMP / render::CPU) timed on
                     this host on a stated row sample of the same workload (rank 0, N = 1 only)
 """
@@ -30,23 +37,27 @@ import torch.distributed as dist  # noqa: E402
 import raymarching_amd as rm  # noqa: E402
 from raymarching_amd import sharding  # noqa: E402
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet (packed FMA); see DESIGN.md for the non-fused limit
+FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet (an FMA every issue slot); DESIGN.md has the non-fused limit
 WORKLOADS = {
     # name: (scene file, params overrides, description)
     "default": ("default.txt", dict(), "configs[1]: shipped scene (Menger iterations 3), 1024x768, SSAA 3x3, 2 lights"),
     "menger2": ("menger2.txt", dict(kernel=1), "configs[0]: Menger iterations 2, 1024x768, SSAA 1, 2 lights"),
     "uhd": ("default.txt", dict(width=3840, height=2160, kernel=4), "configs[2]: shipped scene, 3840x2160, SSAA 4x4, 2 lights"),
+    "closeup6": ("closeup6.txt", dict(), "configs[3]: Menger iterations 6 close-up, 1024x768, SSAA 3x3, 2 lights"),
+    "synthetic": ("synthetic1024.txt", dict(), "configs[4]: 1024 mixed primitives, 8 lights, 1024x768, SSAA 3x3"),
 }
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS))
+    ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exhaustive-leg", action="store_true")
     return ap.parse_args()
 
 
@@ -54,9 +65,11 @@ def cpu_baseline(scene_file, kw):
     """Times the oracle on a bounded row sample of the workload; returns the JSON object."""
     from oracle import rmo
     sc = rmo.Scene(scene_file)
+    if sc.prim_count > 20000:
+        return {"value": None, "unit": "Mrays/s", "cores": rmo.max_threads(), "kind": "port",
+                "sample": f"skipped: {sc.prim_count} primitives per SDF call are out of reach of the brute-force CPU path"}
     p = rmo.default_params(**kw)
     threads = rmo.max_threads()
-    lights = sc.light_count
     step = max(1, p.height // 24)
     rows = (step // 2, p.height, step)                 # ~24 rows spread over the frame
     t0 = time.perf_counter()
@@ -66,18 +79,24 @@ def cpu_baseline(scene_file, kw):
     t0 = time.perf_counter()
     _, cnt1 = sc.render(p, rows=rows1, threads=1)
     t_1 = time.perf_counter() - t0
-    n_rows = len(range(*rows))
-    n_rows1 = len(range(*rows1))
     return {
         "value": round(cnt["rays"] / t_omp / 1e6, 5), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"render::OMP restatement on rows {rows[0]}::{rows[2]} ({n_rows} of {p.height} rows, "
+        "sample": f"render::OMP restatement on rows {rows[0]}::{rows[2]} ({len(range(*rows))} of {p.height} rows, "
                   f"{cnt['rays']} rays, {cnt['sdf_calls']} SDF calls) in {t_omp:.2f} s",
         "single_thread": {
             "value": round(cnt1["rays"] / t_1 / 1e6, 5), "unit": "Mrays/s", "cores": 1,
-            "sample": f"render::CPU restatement on rows {rows1[0]}::{rows1[2]} ({n_rows1} rows, {cnt1['rays']} rays) in {t_1:.2f} s",
+            "sample": f"render::CPU restatement on rows {rows1[0]}::{rows1[2]} ({len(range(*rows1))} rows, {cnt1['rays']} rays) in {t_1:.2f} s",
         },
-        "lights": lights,
     }
+
+
+def executed_flops(c):
+    """FLOPs the trace kernel executed for the counted frame: primitives outside lattices are
+    evaluated at every SDF call, lattice crosses (15 FLOPs) only when visited; 7 per march step."""
+    outside = c["prims"] - c["lattice_prims"]
+    f_outside = c["flops_per_sdf"] - 15 * c["lattice_prims"]
+    lattice_evals = c["prim_evals"] - outside * c["sdf_calls"]
+    return f_outside * c["sdf_calls"] + 15 * lattice_evals + 7 * c["march_steps"]
 
 
 def main():
@@ -85,9 +104,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -99,6 +117,7 @@ def main():
     n_lights = len(scene.lights())
     r = rm.Renderer(local)
     r.set_params(params)
+    r.set_evaluator(a.evaluator == "lattice")
     r.set_scene(scene)
 
     W, H, k = params.width, params.height, params.kernel
@@ -118,10 +137,8 @@ def main():
     frame()
     cnt = r.counters()
     r.set_counting(False)
-    # algorithmic FLOPs per scene SDF call: 11 per sphere, 9 per box, 15 per cross
-    types = [n.type for n in scene.nodes()]
-    flops_per_sdf = 11 * types.count(1) + 9 * types.count(2) + 15 * types.count(3)
-    local_flops = cnt["sdf_calls"] * flops_per_sdf + 7 * cnt["march_steps"]
+    local_exec = executed_flops(cnt)
+    local_algo = cnt["sdf_calls"] * cnt["flops_per_sdf"] + 7 * cnt["march_steps"]
 
     for _ in range(a.warmup):
         frame()
@@ -131,7 +148,7 @@ def main():
     kernel_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = frame()
+        frame()
         kernel_ms += r.counters()["kernel_ms"]
     torch.cuda.synchronize()
     if world > 1:
@@ -139,40 +156,66 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms /= max(1, a.steps)
 
-    stats = torch.tensor([elapsed, kernel_ms, float(local_flops), float(cnt["sdf_calls"])], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])],
+                         dtype=torch.float64, device="cuda")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        kernel_ms_max = float(mx[1])
-        total_flops, total_sdf = float(sm[2]), float(sm[3])
+        elapsed, kernel_ms_max = float(mx[0]), float(mx[1])
+        total_exec, total_algo, total_sdf = float(sm[2]), float(sm[3]), float(sm[4])
     else:
-        kernel_ms_max, total_flops, total_sdf = kernel_ms, float(local_flops), float(cnt["sdf_calls"])
+        kernel_ms_max, total_exec, total_algo, total_sdf = kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])
+
+    # ---- the same kernel with every primitive visited (rank 0's share, a few frames)
+    exhaustive = None
+    if a.evaluator == "lattice" and not a.no_exhaustive_leg and cnt["lattice_prims"] and cnt["prims"] <= 20000:
+        r.set_evaluator(False)
+        r.set_scene(scene)
+        for _ in range(2):
+            r.render_device(rows, None, shard.data_ptr())
+        ms = []
+        for _ in range(3):
+            r.render_device(rows, None, shard.data_ptr())
+            ms.append(r.counters()["kernel_ms"])
+        ex_ms = sum(ms) / len(ms)
+        achieved = local_algo / (ex_ms * 1e-3) / 1e12
+        exhaustive = {"bound": "valu_fp32", "kernel": "trace_kernel<1,4> (one sample per lane, every primitive visited)",
+                      "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(ex_ms, 4),
+                      "mrays_per_s": round(rays_per_frame / world / ex_ms / 1e3, 2) if world == 1 else None}
+        r.set_evaluator(True)
+        r.set_scene(scene)
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_per_frame * a.steps / elapsed / 1e6
-        # dominant kernel: the trace kernel of THIS rank (rank 0), its own flops over its own duration
-        achieved = local_flops / (kernel_ms * 1e-3) / 1e12
+        # dominant kernel: the trace kernel of rank 0, its own executed flops over its own duration
+        achieved = local_exec / (kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "Mrays/s (primary+shadow), default scene", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": scene_name, "width": W, "height": H, "ssaa_kernel": k,
                        "lights": n_lights, "primitives": cnt["prims"], "rays_per_frame": rays_per_frame,
+                       "evaluator": a.evaluator,
                        "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows}, cyclic over {world} ranks, RCCL gather of RGBA8 to rank 0"},
             "roofline": {
                 "bound": "valu_fp32", "kernel": "trace_kernel", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel_ms": round(kernel_ms, 4), "flops_per_sdf_call": flops_per_sdf,
-                "sdf_calls_per_frame": int(total_sdf), "flops_per_frame": int(total_flops),
-                "note": "peak is the packed-FMA datasheet figure; this path has no multiply-adds to fuse (see DESIGN.md)",
+                "kernel_ms": round(kernel_ms, 4), "flops": "executed (counted primitive evaluations)",
+                "executed_flops_per_frame": int(total_exec), "sdf_calls_per_frame": int(total_sdf),
+                "prim_evals_per_sdf_call": round(cnt["prim_evals"] / max(1, cnt["sdf_calls"]), 2),
+                "brute_force_equivalent": {"flops_per_sdf_call": cnt["flops_per_sdf"], "flops_per_frame": int(total_algo),
+                                           "tflops": round(local_algo / (kernel_ms * 1e-3) / 1e12, 2)},
+                "note": "peak is the FMA-every-slot datasheet figure; this path has no multiply-adds to fuse (DESIGN.md)",
             },
             "frame_ms": round(ms_per_step, 4),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }
+        if exhaustive:
+            line["roofline_exhaustive"] = exhaustive
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene_file, kw)
         print(json.dumps(line), flush=True)

@@ -86,6 +86,9 @@ typedef struct rm_counters {
     uint64_t rays;         /* primary + shadow rays                                 */
     uint64_t prims;        /* primitives in the uploaded scene                      */
     uint64_t prim_evals;   /* primitive distance evaluations actually executed      */
+    uint64_t lattice_prims;/* primitives of the scene covered by recognised lattices */
+    uint64_t flops_per_sdf;/* algorithmic FLOPs of one exhaustive scene SDF call:
+                              11 per sphere, 9 per box, 15 per cross                  */
     double   kernel_ms;    /* device time of the trace kernel(s), HIP events        */
     double   resolve_ms;   /* device time of the resolve kernel                     */
 } rm_counters;

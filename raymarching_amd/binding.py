@@ -37,7 +37,8 @@ class Rows(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
-                ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
+                ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("lattice_prims", C.c_uint64),
+                ("flops_per_sdf", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -43,7 +43,9 @@ enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u, FOLD_FIRST = 64u, FOL
 // 32 bytes, wave-uniform, fetched with one scalar load (s_load_dwordx8).
 //   primitive: a = (centre.x, centre.y, centre.z), h = (half.x | radius, half.y, half.z),
 //              prim = depth-first index of the primitive (its row in `colors`)
-//   RUN:       a = (first row, count, kind) as integers
+//   RUN:       a = (first row, count, kind) as integers; the primitives of one list and kind,
+//              gathered in depth-first order (a fold may run in any order: ties between equal
+//              distances are broken by depth-first index, which keeps the earlier child)
 //   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
 //   PUSH, POP: a[0] = slot
 // half = size / 2 is exact in fp32, so precomputing it does not change a bit of
@@ -55,9 +57,10 @@ struct Rec {
     uint32_t prim;
 };
 
-// Table row i describes the i-th primitive in depth-first order:
+// Table row i (rows exist for the primitives of RUN records only):
 //   pa[i] = (center.x, center.y, center.z, half.x or radius)
 //   pb[i] = (half.y, half.z, 0, 0)            (unused by spheres and *_ISO kinds)
+//   row_prim[i] = depth-first index of the primitive (colour row, tie-break rank)
 struct Float4 { float x, y, z, w; };
 
 // ---- Menger lattice tables -------------------------------------------------
@@ -84,7 +87,8 @@ struct SceneView {
     const Rec *recs;
     const Float4 *pa;
     const Float4 *pb;
-    const Float4 *colors;   // rgb per primitive
+    const uint32_t *row_prim;
+    const Float4 *colors;   // rgb per primitive, by depth-first index
     const Float4 *lights;   // xyz per light
     const uint32_t *lattice;   // lattice blocks (staged into LDS by every workgroup)
     uint32_t lattice_words;

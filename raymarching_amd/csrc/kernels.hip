@@ -38,6 +38,7 @@ typedef uint32_t RecWords __attribute__((ext_vector_type(8)));   // one Rec as a
 typedef const __attribute__((address_space(4))) RecWords *ConstRecs;
 typedef float RowWords __attribute__((ext_vector_type(4)));     // one Float4 table row
 typedef const __attribute__((address_space(4))) RowWords *ConstRows;
+typedef const __attribute__((address_space(4))) uint32_t *ConstIndex;
 
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -101,8 +102,9 @@ __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP],
     for (int n = 0; n < NP; ++n) {
         const float c = neg ? -v[n] : v[n];
         if (TRACK) {
-            // std::min / std::max on Surface: the accumulator survives ties
-            const bool take = first || (mx ? (acc[n] < c) : (c < acc[n]));
+            // std::min / std::max on Surface: of two equal distances the earlier child survives
+            // (its depth-first index is lower), whatever order the children are folded in
+            const bool take = first || (mx ? (acc[n] < c) : (c < acc[n])) || (acc[n] == c && vprim[n] < accp[n]);
             acc[n] = take ? c : acc[n];
             accp[n] = take ? vprim[n] : accp[n];
         } else {
@@ -114,7 +116,7 @@ __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP],
 
 // One RUN: `count` table rows of one kind, one fold.
 template <uint32_t KIND, bool NEG, bool MAX, int NP, bool TRACK>
-__device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, uint32_t first,
+__device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, ConstIndex row_prim, uint32_t first,
                                          uint32_t count, const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
     constexpr bool kNeedB = (KIND == K_BOX || KIND == K_CROSS);
 #pragma unroll 4
@@ -132,9 +134,10 @@ __device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, uint32_t fi
             float v = prim_distance<KIND>(a, b, p[n]);
             if (NEG) v = -v;
             if (TRACK) {
-                const bool take = MAX ? (acc[n] < v) : (v < acc[n]);
+                const uint32_t prim = row_prim[i];
+                const bool take = (MAX ? (acc[n] < v) : (v < acc[n])) || (acc[n] == v && prim < accp[n]);
                 acc[n] = take ? v : acc[n];
-                accp[n] = take ? i : accp[n];
+                accp[n] = take ? prim : accp[n];
             } else {
                 acc[n] = MAX ? __builtin_fmaxf(acc[n], v) : __builtin_fminf(acc[n], v);
             }
@@ -146,10 +149,10 @@ template <uint32_t KIND, int NP, bool TRACK>
 __device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t flags, uint32_t first, uint32_t count,
                                               const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
     switch (flags & (FOLD_NEG | FOLD_MAX)) {
-    case 0: fold_run<KIND, false, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
-    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
-    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
-    default: fold_run<KIND, true, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, first, count, p, acc, accp); break;
+    case 0: fold_run<KIND, false, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    default: fold_run<KIND, true, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
     }
 }
 

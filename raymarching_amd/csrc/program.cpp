@@ -197,34 +197,37 @@ struct Compiler {
         }
     }
 
-    // appends the table row of a primitive and returns its index
-    uint32_t add_prim(const rm_node &n) {
-        Float4 a = { n.center[0], n.center[1], n.center[2], 0.0f };
-        Float4 b = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (n.type == RM_SPHERE) {
-            a.w = n.size[0];
-            out.flops_per_sdf += 11;
-        } else {
-            a.w = n.size[0] / 2;
-            b.x = n.size[1] / 2;
-            b.y = n.size[2] / 2;
-            out.flops_per_sdf += (n.type == RM_BOX) ? 9 : 15;
-        }
-        out.pa.push_back(a);
-        out.pb.push_back(b);
+    // Every primitive gets its depth-first index (the order Body::List::SDF visits them): it
+    // names the primitive's colour and breaks ties between equal distances, so that folds may
+    // run in any order and still keep the earlier child, as the sequential fold does.
+    uint32_t new_prim(const rm_node &n) {
+        out.flops_per_sdf += n.type == RM_SPHERE ? 11 : (n.type == RM_BOX ? 9 : 15);
         out.colors.push_back(Float4{ n.color[0], n.color[1], n.color[2], 0.0f });
         return out.n_prims++;
     }
 
-    void emit_single(const rm_node &n, uint32_t fold) {
-        const uint32_t row = add_prim(n);
+    static void halves(const rm_node &n, Float4 &a, Float4 &b) {
+        a = Float4{ n.center[0], n.center[1], n.center[2], 0.0f };
+        b = Float4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        if (n.type == RM_SPHERE) {
+            a.w = n.size[0];
+        } else {
+            a.w = n.size[0] / 2;
+            b.x = n.size[1] / 2;
+            b.y = n.size[2] / 2;
+        }
+    }
+
+    void emit_single(const rm_node &n, uint32_t prim, uint32_t fold) {
+        Float4 a, b;
+        halves(n, a, b);
         Rec r = {};
-        r.a[0] = bits_of(n.center[0]); r.a[1] = bits_of(n.center[1]); r.a[2] = bits_of(n.center[2]);
-        r.h[0] = bits_of(out.pa[row].w);
-        r.h[1] = n.type == RM_SPHERE ? 0u : bits_of(out.pb[row].x);
-        r.h[2] = n.type == RM_SPHERE ? 0u : bits_of(out.pb[row].y);
+        r.a[0] = bits_of(a.x); r.a[1] = bits_of(a.y); r.a[2] = bits_of(a.z);
+        r.h[0] = bits_of(a.w);
+        r.h[1] = n.type == RM_SPHERE ? 0u : bits_of(b.x);
+        r.h[2] = n.type == RM_SPHERE ? 0u : bits_of(b.y);
         r.flags = (n.type == RM_SPHERE ? REC_SPHERE : n.type == RM_BOX ? REC_BOX : REC_CROSS) | fold;
-        r.prim = row;
+        r.prim = prim;
         out.recs.push_back(r);
     }
 
@@ -233,6 +236,7 @@ struct Compiler {
     // number of children consumed; otherwise 0.
     uint32_t try_lattice(uint32_t left, uint32_t fold) {
         if (!use_lattice || fold != (FOLD_MAX | FOLD_NEG)) return 0;
+        if (nodes[cursor].type != RM_CROSS || !iso(nodes[cursor])) return 0;
         // how many consecutive cubic crosses are there
         uint32_t avail = 0;
         while (avail < left && cursor + avail < n_nodes && nodes[cursor + avail].type == RM_CROSS &&
@@ -250,26 +254,38 @@ struct Compiler {
             if (!m.match(levels)) continue;
             const uint32_t count = (uint32_t)lattice_size(levels);
             const uint32_t offset = m.emit(out.lattice);
-            const uint32_t first_row = out.n_prims;
-            for (uint32_t i = 0; i < count; i++) add_prim(nodes[cursor + i]);
+            const uint32_t first_prim = out.n_prims;
+            for (uint32_t i = 0; i < count; i++) new_prim(nodes[cursor + i]);
             Rec r = {};
             r.a[0] = levels; r.a[1] = offset; r.a[2] = count;
             r.flags = REC_LATTICE | fold;
-            r.prim = first_row;
+            r.prim = first_prim;
             out.recs.push_back(r);
             out.n_lattices++;
+            out.lattice_prims += count;
             cursor += count;
             return count;
         }
         return 0;
     }
 
+    struct Bucket {
+        std::vector<uint32_t> node, prim;
+    };
+
     // Compiles the children of the list at nodes[list_at]; cursor is on its first child.
+    //
+    // min and max are commutative and associative on floats, so the children after the first may
+    // be folded in any order as long as ties are broken by depth-first index (the kernels do):
+    // primitives are gathered per kind into RUNs over the tables, nested lists and lattices stay
+    // where they are.
     bool list_body(uint32_t list_at, uint32_t depth) {
         const uint32_t mode = nodes[list_at].mode;
         const uint32_t n_children = nodes[list_at].child_count;
         if (mode > RM_DIFFERENCE) return fail("list node with an unknown mode");
         out.n_lists++;
+        Bucket buckets[K_CROSS_ISO + 1];
+        const uint32_t fold_rest = fold_of(mode, false);
         uint32_t child = 0;
         while (child < n_children) {
             if (cursor >= n_nodes) return fail("node list ends inside a list (child_count too large)");
@@ -291,35 +307,40 @@ struct Compiler {
                 continue;
             }
             if (n.type > RM_CROSS) return fail("node with an unknown type");
-            const uint32_t fold = fold_of(mode, child == 0);
             if (child == 0) {   // the first child replaces the accumulator: always a record of its own
-                emit_single(n, fold);
+                emit_single(n, new_prim(n), fold_of(mode, true));
                 cursor++;
                 child++;
                 continue;
             }
-            if (const uint32_t used = try_lattice(n_children - child, fold)) {
+            if (const uint32_t used = try_lattice(n_children - child, fold_rest)) {
                 child += used;
                 continue;
             }
-            // consecutive primitive children of the same kind: a RUN over the tables if long enough
-            const uint32_t kind = kind_of(n);
-            uint32_t len = 0;
-            while (child + len < n_children && cursor + len < n_nodes && nodes[cursor + len].type != RM_LIST &&
-                   nodes[cursor + len].type <= RM_CROSS && kind_of(nodes[cursor + len]) == kind)
-                len++;
-            if (len >= kRunMin) {
+            Bucket &bk = buckets[kind_of(n)];
+            bk.node.push_back(cursor);
+            bk.prim.push_back(new_prim(n));
+            cursor++;
+            child++;
+        }
+        for (uint32_t kind = K_SPHERE; kind <= K_CROSS_ISO; kind++) {
+            const Bucket &bk = buckets[kind];
+            if (bk.node.size() >= kRunMin) {
                 Rec r = {};
-                r.a[0] = out.n_prims; r.a[1] = len; r.a[2] = kind;
-                r.flags = REC_RUN | fold;
+                r.a[0] = (uint32_t)out.pa.size(); r.a[1] = (uint32_t)bk.node.size(); r.a[2] = kind;
+                r.flags = REC_RUN | fold_rest;
                 out.recs.push_back(r);
-                out.run_prims += len;
-                for (uint32_t i = 0; i < len; i++) add_prim(nodes[cursor + i]);
+                out.run_prims += (uint32_t)bk.node.size();
+                for (size_t i = 0; i < bk.node.size(); i++) {
+                    Float4 a, b;
+                    halves(nodes[bk.node[i]], a, b);
+                    out.pa.push_back(a);
+                    out.pb.push_back(b);
+                    out.row_prim.push_back(bk.prim[i]);
+                }
             } else {
-                for (uint32_t i = 0; i < len; i++) emit_single(nodes[cursor + i], fold);
+                for (size_t i = 0; i < bk.node.size(); i++) emit_single(nodes[bk.node[i]], bk.prim[i], fold_rest);
             }
-            cursor += len;
-            child += len;
         }
         return true;
     }
@@ -349,8 +370,9 @@ bool compile_scene(const rm_node *nodes, uint32_t n_nodes, bool use_lattice, Hos
     if (out.pa.empty()) {
         out.pa.push_back(Float4{ 0, 0, 0, 0 });
         out.pb.push_back(Float4{ 0, 0, 0, 0 });
-        out.colors.push_back(Float4{ 0, 0, 0, 0 });
+        out.row_prim.push_back(0u);
     }
+    if (out.colors.empty()) out.colors.push_back(Float4{ 0, 0, 0, 0 });
     if (out.lattice.empty()) out.lattice.push_back(0u);
     return true;
 }

@@ -12,9 +12,12 @@ namespace rmdev {
 
 struct HostProgram {
     std::vector<Rec> recs;
-    std::vector<Float4> pa, pb, colors;
+    std::vector<Float4> pa, pb;      // table rows of the RUN records
+    std::vector<uint32_t> row_prim;  // depth-first primitive index of every table row
+    std::vector<Float4> colors;      // rgb per primitive, by depth-first index
     std::vector<uint32_t> lattice;   // Menger lattice blocks (device_scene.h)
     uint32_t n_lattices = 0;
+    uint32_t lattice_prims = 0;      // primitives covered by LATTICE records
     uint32_t n_prims = 0;
     uint32_t run_prims = 0;          // primitives evaluated through RUN records (table rows)
     uint32_t n_lists = 0;

@@ -126,3 +126,41 @@ def test_menger4_frame_bit_identical(rm, oracle, renderer):
     gpu = renderer.render_f32()
     cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
     assert gpu.tobytes() == cpu.tobytes()
+
+
+def test_closeup6_points_and_tiny_frame(rm, oracle, renderer):
+    """configs[3]: Menger iterations 6 (3 368 421 crosses) with the close-up camera.  The brute-force
+    oracle needs ~70 ms per SDF call here, so the check is a handful of points and a 6x4 frame."""
+    path = scene_path("closeup6.txt")
+    prod, orc = rm.Scene(path), oracle.Scene(path)
+    assert orc.prim_count == 7 + 3368421
+    renderer.set_scene(prod)
+    rng = np.random.default_rng(6)
+    pts = sponge_points(rng, 96, (0, 10, -50), 20.0)
+    sd, _ = renderer.eval_sdf(pts)
+    osd, _ = orc.sdf(pts)
+    assert sd.tobytes() == osd.tobytes()
+    kw = dict(width=6, height=4, kernel=1)
+    renderer.set_params(rm.default_params(**kw))
+    gpu = renderer.render_f32()
+    cpu, _ = orc.render(oracle.default_params(**kw))
+    assert gpu.tobytes() == cpu.tobytes()
+
+
+def test_synthetic1024_frame_bit_identical(rm, oracle, renderer):
+    """configs[4]: 1024 mixed primitives in the root union, 8 lights; small frame against the oracle."""
+    path = scene_path("synthetic1024.txt")
+    kw = dict(width=80, height=60, kernel=2)
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(path))
+    gpu = renderer.render_f32()
+    orc = oracle.Scene(path)
+    assert (orc.prim_count, orc.light_count) == (1026, 8)
+    cpu, _ = orc.render(oracle.default_params(**kw))
+    assert gpu.tobytes() == cpu.tobytes()
+    pts = np.random.default_rng(3).uniform([-70, -2, -120], [70, 40, 20], (5000, 3)).astype(np.float32)
+    sd, prim = renderer.eval_sdf(pts)
+    osd, orgb = orc.sdf(pts)
+    assert sd.tobytes() == osd.tobytes()
+    colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)
+    np.testing.assert_array_equal(colours[prim], orgb)

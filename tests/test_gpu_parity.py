@@ -228,3 +228,32 @@ def test_errors_are_reported(rm):
         r.close()
     with pytest.raises(rm.RaymarchError, match="no HIP device"):
         rm.Renderer(99)
+
+
+@pytest.mark.parametrize("copies", [1, 5])
+@pytest.mark.parametrize("mode", [UNION, INTERSECTION, COMPLEMENT, DIFFERENCE])
+def test_ties_between_kinds_keep_the_earlier_child(rm, oracle, renderer, mode, copies):
+    """Primitives of one list are regrouped per kind before they are folded; of two children at exactly
+    the same distance the earlier one (in the list's order) must still win, as in the sequential fold.
+    copies = 1 exercises single records, copies = 5 the table RUNs."""
+    spec = [(LIST, mode, 0, (0, 0, 0), (0, 0, 0), (0, 0, 0)),
+            (SPHERE, 0, 0, (0, 40, 0), (1, 0, 0), (0.1, 0.1, 0.1))]       # first child, far away
+    pts = []
+    for c in range(copies):
+        z = 10.0 * c
+        # box (half 1) at x=+3 comes BEFORE the sphere (r=1) at x=-3 and the cross at y=+3: all are at
+        # distance 2 from (0,0,z); spheres are folded before boxes after regrouping
+        spec.append((BOX, 0, 0, (3, 0, z), (2, 2, 2), (1, 0, 0)))
+        spec.append((SPHERE, 0, 0, (-3, 0, z), (1, 0, 0), (0, 1, 0)))
+        spec.append((CROSS, 0, 0, (0, 3, z + 0.0), (2, 2, 2), (0, 0, 1)))
+        pts.append((0, 0, z))
+    spec[0] = (LIST, mode, len(spec) - 1, (0, 0, 0), (0, 0, 0), (0, 0, 0))
+    pnodes, onodes = _mk(rm.Node, spec), _mk(oracle.Node, spec)
+    renderer.set_scene_raw(pnodes, np.zeros((0, 3), np.float32), np.eye(4, dtype=np.float32).reshape(-1), 1.0)
+    pts = np.array(pts, np.float32)
+    sd, prim = renderer.eval_sdf(pts)
+    orc = oracle.Scene(nodes=onodes)
+    osd, orgb = orc.sdf(pts)
+    assert sd.tobytes() == osd.tobytes()
+    colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)
+    np.testing.assert_array_equal(colours[prim], orgb)
