@@ -75,7 +75,7 @@ struct rm_context {
     DeviceArray<float> d_frame_f32;
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
-    DeviceArray<float> d_points, d_sd;
+    DeviceArray<float> d_points, d_sd, d_camera;
     DeviceArray<uint32_t> d_prim, d_lattice, d_row_prim;
 
     rm_counters last{};
@@ -177,7 +177,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_recs.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
     ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
-    ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release();
+    ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -211,6 +211,10 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(ctx->d_lights.reserve(n_lights));
     RM_HIP(ctx->d_lattice.reserve(prog.lattice.size()));
     RM_HIP(ctx->d_row_prim.reserve(prog.row_prim.size()));
+    RM_HIP(ctx->d_camera.reserve(17));
+    float camera[17];
+    std::memcpy(camera, transform, 16 * sizeof(float));
+    camera[16] = focal;
     std::vector<rmdev::Float4> lights(n_lights ? n_lights : 1, rmdev::Float4{ 0, 0, 0, 0 });
     for (uint32_t i = 0; i < n_lights; i++)
         lights[i] = rmdev::Float4{ lights_xyz[3 * i], lights_xyz[3 * i + 1], lights_xyz[3 * i + 2], 0.0f };
@@ -219,18 +223,18 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(hipMemcpyAsync(ctx->d_pb.ptr, prog.pb.data(), prog.pb.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_colors.ptr, prog.colors.data(), prog.colors.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_lights.ptr, lights.data(), lights.size() * sizeof(rmdev::Float4), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->d_camera.ptr, camera, sizeof camera, hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_row_prim.ptr, prog.row_prim.data(), prog.row_prim.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->d_lattice.ptr, prog.lattice.data(), prog.lattice.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
     ctx->program = std::move(prog);
     rmdev::SceneView &sv = ctx->scene;
-    sv.recs = ctx->d_recs.ptr; sv.n_recs = static_cast<uint32_t>(ctx->program.recs.size()) - 1u; sv.max_depth = ctx->program.max_depth; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr; sv.row_prim = ctx->d_row_prim.ptr;
+    sv.recs = ctx->d_recs.ptr; sv.n_recs = static_cast<uint32_t>(ctx->program.recs.size()) - 1u; sv.max_depth = ctx->program.max_depth; sv.root_identity = ctx->program.root_identity; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr; sv.row_prim = ctx->d_row_prim.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
     sv.lattice = ctx->d_lattice.ptr;
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
-    std::memcpy(sv.cam, transform, sizeof sv.cam);
-    sv.focal = focal;
+    sv.camera = ctx->d_camera.ptr;
     ctx->have_scene = true;
     return RM_OK;
 }

@@ -16,13 +16,15 @@
 //                          into the parked one
 //   END
 //
-// fold = {negate the child?, keep the larger (max) or the smaller (min)?, is this the
-// list's first child (then the child replaces the accumulator)?}:
+// fold = {negate the child?, keep the larger (max) or the smaller (min)?}:
 //   UNION         first: s = c     then s = min(s,  c)
 //   COMPLEMENT    first: s = -c    then s = min(s, -c)
 //   INTERSECTION  first: s = c     then s = max(s,  c)
 //   DIFFERENCE    first: s = c     then s = max(s, -c)
-// min/max keep the accumulator on ties (std::min/std::max semantics).
+// A list's accumulator starts at its fold's identity (+inf for min, -inf for max), so the first
+// child needs no special case: it is folded like the others (DIFFERENCE's first child without the
+// negation).  An empty list yields +inf.  min/max keep the earlier child on ties
+// (std::min/std::max semantics).
 #pragma once
 
 #include <cstdint>
@@ -38,7 +40,7 @@ enum RecCode : uint32_t {
 enum Kind : uint32_t { K_SPHERE = 1, K_BOX = 2, K_CROSS = 3, K_BOX_ISO = 4, K_CROSS_ISO = 5 };
 
 // fold bits as they sit in Rec::flags (above the 4-bit record code)
-enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u, FOLD_FIRST = 64u, FOLD_MASK = 112u };
+enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u };
 
 // 32 bytes, wave-uniform, fetched with one scalar load (s_load_dwordx8).
 //   primitive: a = (centre.x, centre.y, centre.z), h = (half.x | radius, half.y, half.z),
@@ -47,7 +49,8 @@ enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u, FOLD_FIRST = 64u, FOL
 //              gathered in depth-first order (a fold may run in any order: ties between equal
 //              distances are broken by depth-first index, which keeps the earlier child)
 //   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
-//   PUSH, POP: a[0] = slot
+//   PUSH:      a[0] = slot, a[1] = identity of the list that starts (float bits)
+//   POP:       a[0] = slot
 // half = size / 2 is exact in fp32, so precomputing it does not change a bit of
 // "abs(p - c) - size / 2" (body.cpp:42, :52).
 struct Rec {
@@ -93,11 +96,11 @@ struct SceneView {
     const uint32_t *lattice;   // lattice blocks (staged into LDS by every workgroup)
     uint32_t lattice_words;
     uint32_t n_recs;        // records before the END record
+    float root_identity;    // the root list's starting accumulator
     uint32_t max_depth;     // deepest PUSH slot + 1 (sizes the LDS parking area)
     uint32_t n_lights;
     uint32_t n_prims;
-    float cam[16];          // column-major camera matrix
-    float focal;
+    const float *camera;    // 16 floats of the column-major camera matrix, then the focal length
 };
 
 struct FrameView {

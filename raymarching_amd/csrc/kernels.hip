@@ -39,6 +39,7 @@ typedef const __attribute__((address_space(4))) RecWords *ConstRecs;
 typedef float RowWords __attribute__((ext_vector_type(4)));     // one Float4 table row
 typedef const __attribute__((address_space(4))) RowWords *ConstRows;
 typedef const __attribute__((address_space(4))) uint32_t *ConstIndex;
+typedef const __attribute__((address_space(4))) float *ConstFloats;
 
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -97,19 +98,18 @@ __device__ __forceinline__ float prim_distance(const Float4 a, const Float4 b, V
 template <int NP, bool TRACK>
 __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
                                            float (&acc)[NP], uint32_t (&accp)[NP]) {
-    const bool neg = (flags & FOLD_NEG) != 0, mx = (flags & FOLD_MAX) != 0, first = (flags & FOLD_FIRST) != 0;
+    const bool neg = (flags & FOLD_NEG) != 0, mx = (flags & FOLD_MAX) != 0;
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
         const float c = neg ? -v[n] : v[n];
         if (TRACK) {
             // std::min / std::max on Surface: of two equal distances the earlier child survives
             // (its depth-first index is lower), whatever order the children are folded in
-            const bool take = first || (mx ? (acc[n] < c) : (c < acc[n])) || (acc[n] == c && vprim[n] < accp[n]);
+            const bool take = (mx ? (acc[n] < c) : (c < acc[n])) || (acc[n] == c && vprim[n] < accp[n]);
             acc[n] = take ? c : acc[n];
             accp[n] = take ? vprim[n] : accp[n];
         } else {
-            const float f = mx ? __builtin_fmaxf(acc[n], c) : __builtin_fminf(acc[n], c);
-            acc[n] = first ? c : f;
+            acc[n] = mx ? __builtin_fmaxf(acc[n], c) : __builtin_fminf(acc[n], c);
         }
     }
 }
@@ -262,21 +262,64 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
     acc = run;
 }
 
-// Body::List::SDF for the whole tree (body.cpp:66-111) at NP points per lane.
-// TRACK = false: distance only (march steps, gradient taps, shadow rays).
-// TRACK = true : also the depth-first index of the primitive whose colour the resulting Surface
-//                carries.
-// n_evals[n] counts the primitive evaluations spent on point n (COUNT only).
-template <int NP, bool TRACK, bool COUNT>
-__device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
-                                               uint32_t (&out_prim)[NP], uint32_t (&n_evals)[NP]) {
-    const float inf = __builtin_inff();
-    float acc[NP];
-    uint32_t accp[NP];
+// ---- Body::List::SDF for the whole tree (body.cpp:66-111) at NP points per lane ----------------
+//
+// Two walkers over the same record stream:
+//   scene_sd        distance only (march steps, gradient taps, shadow rays): the hot one.  Every
+//                   (record kind, fold) pair is a case of one switch with the fold compiled in, so
+//                   a record costs a handful of scalar instructions and no selects.
+//   scene_surface   distance and the depth-first index of the primitive whose colour the resulting
+//                   Surface carries (once per sample, and the rm_eval_sdf test hook).
+// A list's accumulator starts from its fold's identity (+inf for min, -inf for max; the host puts
+// it into the PUSH record and SceneView::root_identity), so "the first child replaces the
+// accumulator" needs no case of its own; an empty list keeps +inf / no colour.
+
+template <bool NEG, bool MAX>
+__device__ __forceinline__ float fold_sd(float acc, float v) {
+    return MAX ? __builtin_fmaxf(acc, NEG ? -v : v) : __builtin_fminf(acc, NEG ? -v : v);
+}
+
+template <uint32_t CODE, bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void single_sd(const RecWords &r, const V3 (&p)[NP], float (&acc)[NP]) {
+    const float cx = __uint_as_float(r[0]), cy = __uint_as_float(r[1]), cz = __uint_as_float(r[2]);
+    const float h0 = __uint_as_float(r[3]), h1 = __uint_as_float(r[4]), h2 = __uint_as_float(r[5]);
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-        acc[n] = inf;   // an empty list is +inf / colour 0
-        accp[n] = kNoPrim;
+        float v;
+        if (CODE == REC_SPHERE) {
+            const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
+            v = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
+        } else {
+            const float dx = __builtin_fabsf(p[n].x - cx) - h0;
+            const float dy = __builtin_fabsf(p[n].y - cy) - h1;
+            const float dz = __builtin_fabsf(p[n].z - cz) - h2;
+            v = CODE == REC_CROSS ? cross_value(dx, dy, dz) : __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+        }
+        acc[n] = fold_sd<NEG, MAX>(acc[n], v);
+    }
+}
+
+template <bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void pop_sd(const uint32_t *slot, float (&acc)[NP]) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) acc[n] = fold_sd<NEG, MAX>(__uint_as_float(slot[n * 256]), acc[n]);
+}
+
+#define RM_FOLD_CASES(CODE, CALL)                                   \
+    case CODE: { CALL(false, false); } break;                       \
+    case CODE | FOLD_NEG: { CALL(true, false); } break;             \
+    case CODE | FOLD_MAX: { CALL(false, true); } break;             \
+    case CODE | FOLD_NEG | FOLD_MAX: { CALL(true, true); } break;
+
+template <int NP, bool COUNT>
+__device__ __forceinline__ void scene_sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
+                                         uint32_t (&n_evals)[NP]) {
+    float acc[NP];
+    uint32_t no_prim[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        acc[n] = sc.root_identity;
+        no_prim[n] = kNoPrim;
     }
     // Records are fetched one ahead: the scalar load of record pc + 1 is in flight while record pc
     // is evaluated (the stream ends with an END record, so pc + 1 is always readable).
@@ -288,68 +331,113 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
         // record pc first (lgkmcnt(0)), then put record pc + 1 in flight behind it
         __builtin_amdgcn_s_waitcnt(0xc07f);
         next = recs[pc + 1];
-        Rec r;
-        r.a[0] = cur[0]; r.a[1] = cur[1]; r.a[2] = cur[2];
-        r.h[0] = cur[3]; r.h[1] = cur[4]; r.h[2] = cur[5];
-        r.flags = cur[6];
-        r.prim = cur[7];
-        const uint32_t code = r.flags & 15u;
-        if (code <= REC_CROSS) {
-            float v[NP];
-            uint32_t vp[NP];
-            const float cx = __uint_as_float(r.a[0]), cy = __uint_as_float(r.a[1]), cz = __uint_as_float(r.a[2]);
-            const float h0 = __uint_as_float(r.h[0]), h1 = __uint_as_float(r.h[1]), h2 = __uint_as_float(r.h[2]);
-            if (code == REC_SPHERE) {
-#pragma unroll
-                for (int n = 0; n < NP; ++n) {
-                    const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
-                    v[n] = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
-                }
-            } else {
-#pragma unroll
-                for (int n = 0; n < NP; ++n) {
-                    const float dx = __builtin_fabsf(p[n].x - cx) - h0;
-                    const float dy = __builtin_fabsf(p[n].y - cy) - h1;
-                    const float dz = __builtin_fabsf(p[n].z - cz) - h2;
-                    const float dmin = __builtin_fminf(__builtin_fminf(dx, dy), dz);
-                    const float dmax = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
-                    v[n] = (code == REC_CROSS) ? (dx + dy + dz - dmin - dmax) : dmax;
-                }
-            }
+        switch (cur[6] & 63u) {
+#define RM_SPHERE(NEG, MAX) single_sd<REC_SPHERE, NEG, MAX, NP>(cur, p, acc)
+#define RM_BOX(NEG, MAX) single_sd<REC_BOX, NEG, MAX, NP>(cur, p, acc)
+#define RM_CROSS(NEG, MAX) single_sd<REC_CROSS, NEG, MAX, NP>(cur, p, acc)
+#define RM_POP(NEG, MAX) pop_sd<NEG, MAX, NP>(lds.park + cur[0] * (2u * kMaxPts * 256u) + threadIdx.x, acc)
+            RM_FOLD_CASES(REC_SPHERE, RM_SPHERE)
+            RM_FOLD_CASES(REC_BOX, RM_BOX)
+            RM_FOLD_CASES(REC_CROSS, RM_CROSS)
+            RM_FOLD_CASES(REC_POP, RM_POP)
+#undef RM_SPHERE
+#undef RM_BOX
+#undef RM_CROSS
+#undef RM_POP
+        case REC_PUSH: {
+            uint32_t *slot = lds.park + cur[0] * (2u * kMaxPts * 256u) + threadIdx.x;
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
-                vp[n] = r.prim;
-                if (COUNT) n_evals[n] += 1;
+                slot[n * 256] = __float_as_uint(acc[n]);
+                acc[n] = __uint_as_float(cur[1]);   // the new list's identity
             }
-            fold_value<NP, TRACK>(r.flags, v, vp, acc, accp);
-        } else if (code == REC_RUN) {
-            const uint32_t first = r.a[0], count = r.a[1], kind = r.a[2];
+        } break;
+        case REC_LATTICE | FOLD_NEG | FOLD_MAX: {
+#pragma unroll
+            for (int n = 0; n < NP; ++n)
+                lattice_fold<false, COUNT>(lds.lattice + cur[1], cur[0], cur[7], p[n], acc[n], no_prim[n], n_evals[n]);
+        } break;
+        default: {   // REC_RUN with any fold
+            const uint32_t first = cur[0], count = cur[1], kind = cur[2];
             if (COUNT) {
 #pragma unroll
                 for (int n = 0; n < NP; ++n) n_evals[n] += count;
             }
             switch (kind) {
-            case K_SPHERE: fold_run_kind<K_SPHERE, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
-            case K_BOX: fold_run_kind<K_BOX, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
-            case K_CROSS: fold_run_kind<K_CROSS, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
-            case K_BOX_ISO: fold_run_kind<K_BOX_ISO, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
-            default: fold_run_kind<K_CROSS_ISO, NP, TRACK>(sc, r.flags, first, count, p, acc, accp); break;
+            case K_SPHERE: fold_run_kind<K_SPHERE, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
+            case K_BOX: fold_run_kind<K_BOX, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
+            case K_CROSS: fold_run_kind<K_CROSS, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
+            case K_BOX_ISO: fold_run_kind<K_BOX_ISO, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
+            default: fold_run_kind<K_CROSS_ISO, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
+            }
+        } break;
+        }
+        if (COUNT && (cur[6] & 15u) <= REC_CROSS) {
+#pragma unroll
+            for (int n = 0; n < NP; ++n) n_evals[n] += 1;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NP; ++n) out_sd[n] = acc[n];
+}
+
+template <int NP>
+__device__ __forceinline__ void scene_surface(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
+                                              uint32_t (&out_prim)[NP]) {
+    float acc[NP];
+    uint32_t accp[NP], evals_unused[NP] = {};
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        acc[n] = sc.root_identity;
+        accp[n] = kNoPrim;
+    }
+    const ConstRecs recs = (ConstRecs)(sc.recs);
+    for (uint32_t pc = 0; pc < sc.n_recs; ++pc) {
+        const RecWords r = recs[pc];
+        const uint32_t code = r[6] & 15u;
+        if (code <= REC_CROSS) {
+            float v[NP];
+            uint32_t vp[NP];
+            const float cx = __uint_as_float(r[0]), cy = __uint_as_float(r[1]), cz = __uint_as_float(r[2]);
+            const float h0 = __uint_as_float(r[3]), h1 = __uint_as_float(r[4]), h2 = __uint_as_float(r[5]);
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                if (code == REC_SPHERE) {
+                    const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
+                    v[n] = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
+                } else {
+                    const float dx = __builtin_fabsf(p[n].x - cx) - h0;
+                    const float dy = __builtin_fabsf(p[n].y - cy) - h1;
+                    const float dz = __builtin_fabsf(p[n].z - cz) - h2;
+                    v[n] = code == REC_CROSS ? cross_value(dx, dy, dz) : __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+                }
+                vp[n] = r[7];
+            }
+            fold_value<NP, true>(r[6], v, vp, acc, accp);
+        } else if (code == REC_RUN) {
+            const uint32_t first = r[0], count = r[1], kind = r[2];
+            switch (kind) {
+            case K_SPHERE: fold_run_kind<K_SPHERE, NP, true>(sc, r[6], first, count, p, acc, accp); break;
+            case K_BOX: fold_run_kind<K_BOX, NP, true>(sc, r[6], first, count, p, acc, accp); break;
+            case K_CROSS: fold_run_kind<K_CROSS, NP, true>(sc, r[6], first, count, p, acc, accp); break;
+            case K_BOX_ISO: fold_run_kind<K_BOX_ISO, NP, true>(sc, r[6], first, count, p, acc, accp); break;
+            default: fold_run_kind<K_CROSS_ISO, NP, true>(sc, r[6], first, count, p, acc, accp); break;
             }
         } else if (code == REC_LATTICE) {
 #pragma unroll
             for (int n = 0; n < NP; ++n)
-                lattice_fold<TRACK, COUNT>(lds.lattice + r.a[1], r.a[0], r.prim, p[n], acc[n], accp[n], n_evals[n]);
+                lattice_fold<true, false>(lds.lattice + r[1], r[0], r[7], p[n], acc[n], accp[n], evals_unused[n]);
         } else if (code == REC_PUSH) {
-            uint32_t *slot = lds.park + r.a[0] * (2u * kMaxPts * 256u) + threadIdx.x;
+            uint32_t *slot = lds.park + r[0] * (2u * kMaxPts * 256u) + threadIdx.x;
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
                 slot[n * 256] = __float_as_uint(acc[n]);
-                if (TRACK) slot[(kMaxPts + n) * 256] = accp[n];
-                acc[n] = inf;
+                slot[(kMaxPts + n) * 256] = accp[n];
+                acc[n] = __uint_as_float(r[1]);
                 accp[n] = kNoPrim;
             }
         } else {   // REC_POP: the finished list is one child of the parked accumulator
-            const uint32_t *slot = lds.park + r.a[0] * (2u * kMaxPts * 256u) + threadIdx.x;
+            const uint32_t *slot = lds.park + r[0] * (2u * kMaxPts * 256u) + threadIdx.x;
             float v[NP];
             uint32_t vp[NP];
 #pragma unroll
@@ -357,9 +445,9 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
                 v[n] = acc[n];
                 vp[n] = accp[n];
                 acc[n] = __uint_as_float(slot[n * 256]);
-                if (TRACK) accp[n] = slot[(kMaxPts + n) * 256];
+                accp[n] = slot[(kMaxPts + n) * 256];
             }
-            fold_value<NP, TRACK>(r.flags, v, vp, acc, accp);
+            fold_value<NP, true>(r[6], v, vp, acc, accp);
         }
     }
 #pragma unroll
@@ -369,7 +457,7 @@ __device__ __forceinline__ void scene_distance(const SceneView &sc, const Lds &l
     }
 }
 
-__device__ __forceinline__ V3 camera_view(const float *m, V3 v, float w) {
+__device__ __forceinline__ V3 camera_view(ConstFloats m, V3 v, float w) {
     return v3(v.x * m[0] + v.y * m[4] + v.z * m[8] + w * m[12], v.x * m[1] + v.y * m[5] + v.z * m[9] + w * m[13],
               v.x * m[2] + v.y * m[6] + v.z * m[10] + w * m[14]);
 }
@@ -398,8 +486,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
         if (all_done) break;
         float sd[kPts];
-        uint32_t prim[kPts], evals[kPts] = {};
-        scene_distance<kPts, false, COUNT>(sc, lds, p, sd, prim, evals);
+        uint32_t evals[kPts] = {};
+        scene_sd<kPts, COUNT>(sc, lds, p, sd, evals);
 #pragma unroll
         for (int s = 0; s < kPts; ++s) {
             if (!done[s]) {
@@ -440,12 +528,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
     const float AR = (float)fr.width / (float)fr.height;
-    const float w = sc.focal;
+    const ConstFloats cam = (ConstFloats)sc.camera;   // 16 matrix floats, then the focal length
+    const float w = cam[16];
     const float h = w / AR;
     const float s1x = -w / 2, s1y = h / 2;
     const float s2x = w / 2, s2y = -h / 2;
     const float psx = 1.0f / (float)fr.width, psy = 1.0f / (float)fr.height;
-    const V3 origin = camera_view(sc.cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
+    const V3 origin = camera_view(cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
     const uint32_t ly = sy / k, j = sy - ly * k;   // local pixel row, sub-sample row (inner loop index)
     const uint32_t band = ly / fr.band_rows;
     const uint32_t pi = (fr.first_band + band * fr.band_stride) * fr.band_rows + (ly - band * fr.band_rows);
@@ -455,18 +544,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
     const float y = lerp1(p1y, p2y, uvy);
 
     bool stored[kPts], live[kPts];
-    V3 cam_ray[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
-        const uint32_t sx = sx0 + (uint32_t)s;
-        stored[s] = sx < sw && sy < sh;
+        stored[s] = sx0 + (uint32_t)s < sw && sy < sh;
         live[s] = stored[s] && pi < fr.height;
-        const uint32_t pj = sx / k, i = sx - pj * k;   // pixel column, sub-sample column (outer loop index)
-        const float uv1x = (float)pj * psx, uv2x = (float)(pj + 1u) * psx;
-        const float p1x = lerp1(s1x, s2x, uv1x), p2x = lerp1(s1x, s2x, uv2x);
-        const float uvx = (float)(i + 1u) / (float)k;
-        const float x = lerp1(p1x, p2x, uvx);
-        cam_ray[s] = camera_view(sc.cam, normalize3(v3(x, y, -1.0f)), 0.0f);
     }
 
     // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
@@ -488,8 +569,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) {
+                const uint32_t sx = sx0 + (uint32_t)s;
+                const uint32_t pj = sx / k, i = sx - pj * k;   // pixel column, sub-sample column (outer loop index)
+                const float uv1x = (float)pj * psx, uv2x = (float)(pj + 1u) * psx;
+                const float p1x = lerp1(s1x, s2x, uv1x), p2x = lerp1(s1x, s2x, uv2x);
+                const float uvx = (float)(i + 1u) / (float)k;
+                const float x = lerp1(p1x, p2x, uvx);
                 p[s] = origin;
-                ray[s] = cam_ray[s];
+                ray[s] = camera_view(cam, normalize3(v3(x, y, -1.0f)), 0.0f);
             }
         } else {
             const RowWords lp = ((ConstRows)sc.lights)[r - 1];
@@ -509,8 +596,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
             // the Surface scene::surface returned: colour of the last evaluation
             if (fr.iterations > 0) {
                 float sd_unused[kPts];
-                uint32_t evals_unused[kPts] = {};
-                scene_distance<kPts, true, false>(sc, lds, at, sd_unused, prim, evals_unused);
+                scene_surface<kPts>(sc, lds, at, sd_unused, prim);
             }
             // scene::grad, scene.cpp:70-89: six taps, one evaluator instance
             const float hh = 1e-3f;
@@ -527,8 +613,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
                         q[s] = side == 0 ? v3(hit[s].x + e.x, hit[s].y + e.y, hit[s].z + e.z)
                                          : v3(hit[s].x - e.x, hit[s].y - e.y, hit[s].z - e.z);
                     float sd[kPts];
-                    uint32_t prim_unused[kPts], evals[kPts] = {};
-                    scene_distance<kPts, false, COUNT>(sc, lds, q, sd, prim_unused, evals);
+                    uint32_t evals[kPts] = {};
+                    scene_sd<kPts, COUNT>(sc, lds, q, sd, evals);
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) {
                         if (COUNT && live[s]) {
@@ -631,8 +717,8 @@ __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const
     const uint32_t tt = t < n ? t : n - 1;   // every lane walks the scene (nested lists park through LDS)
     const V3 p[1] = { v3(xyz[3 * tt], xyz[3 * tt + 1], xyz[3 * tt + 2]) };
     float d[1];
-    uint32_t pr[1], evals[1] = {};
-    scene_distance<1, true, false>(sc, lds, p, d, pr, evals);
+    uint32_t pr[1];
+    scene_surface<1>(sc, lds, p, d, pr);
     if (t < n) {
         sd[t] = d[0];
         prim[t] = pr[0];

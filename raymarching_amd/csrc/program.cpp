@@ -177,7 +177,7 @@ struct Compiler {
     }
 
     static uint32_t fold_of(uint32_t mode, bool first) {
-        uint32_t f = first ? FOLD_FIRST : 0u;
+        uint32_t f = 0u;
         switch (mode) {
         case RM_UNION: break;
         case RM_COMPLEMENT: f |= FOLD_NEG; break;
@@ -185,6 +185,12 @@ struct Compiler {
         case RM_DIFFERENCE: f |= FOLD_MAX; if (!first) f |= FOLD_NEG; break;
         }
         return f;
+    }
+
+    // starting accumulator of a list: the identity of its fold; an empty list is +inf
+    static float identity_of(const rm_node &list) {
+        const bool is_max = list.mode == RM_INTERSECTION || list.mode == RM_DIFFERENCE;
+        return (is_max && list.child_count > 0) ? -INFINITY : INFINITY;
     }
 
     static bool iso(const rm_node &n) { return n.size[0] == n.size[1] && n.size[1] == n.size[2]; }
@@ -295,6 +301,7 @@ struct Compiler {
                 const uint32_t at = cursor++;
                 Rec push = {};
                 push.a[0] = depth;
+                push.a[1] = bits_of(identity_of(nodes[at]));
                 push.flags = REC_PUSH;
                 out.recs.push_back(push);
                 if (depth + 1 > out.max_depth) out.max_depth = depth + 1;
@@ -360,6 +367,7 @@ bool compile_scene(const rm_node *nodes, uint32_t n_nodes, bool use_lattice, Hos
     }
     Compiler c{ nodes, n_nodes, use_lattice, out, error };
     c.cursor = 1;
+    out.root_identity = Compiler::identity_of(nodes[0]);
     if (!c.list_body(0, 0)) return false;
     if (c.cursor != n_nodes) {
         error = "nodes left over after the root list's children";

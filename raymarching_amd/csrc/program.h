@@ -22,6 +22,7 @@ struct HostProgram {
     uint32_t run_prims = 0;          // primitives evaluated through RUN records (table rows)
     uint32_t n_lists = 0;
     uint32_t max_depth = 0;
+    float root_identity = 0.0f;      // starting accumulator of the root list
     // algorithmic cost of one scene SDF evaluation: 11 per sphere, 9 per box,
     // 15 per cross (primitive arithmetic + the one compare/select of the fold)
     uint64_t flops_per_sdf = 0;
