@@ -1,0 +1,297 @@
+// device_core.h -- device-side building blocks of the sphere-tracing kernels: vector helpers,
+// primitive distances (body.cpp:32-57), folds, the exact LATTICE evaluator and the LDS layout.
+// Included by the ahead-of-time kernels (kernels.hip) and, as text, by the kernels that are
+// specialised for one scene at upload time (jit.cpp); it therefore includes nothing but
+// device_scene.h.
+#pragma once
+
+#include "device_scene.h"
+
+namespace rmdev {
+
+constexpr int kMaxPts = 2;   // most points per lane and scene walk (sizes the LDS parking area)
+
+struct V3 {
+    float x, y, z;
+};
+
+typedef uint32_t RecWords __attribute__((ext_vector_type(8)));   // one Rec as a single 32-byte scalar load
+
+// Scene tables are never written while a kernel runs: reading them through the constant address
+// space keeps their wave-uniform loads on the scalar unit whatever else the kernel does.
+typedef const __attribute__((address_space(4))) RecWords *ConstRecs;
+typedef float RowWords __attribute__((ext_vector_type(4)));     // one Float4 table row
+typedef const __attribute__((address_space(4))) RowWords *ConstRows;
+typedef const __attribute__((address_space(4))) uint32_t *ConstIndex;
+typedef const __attribute__((address_space(4))) float *ConstFloats;
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// normalize(a) = a * (1 / sqrt(dot(a, a)))
+__device__ __forceinline__ V3 normalize3(V3 a) {
+    const float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+    return a * inv;
+}
+
+// ---- LDS: lattice tables, then the parking area of nested lists -------------
+
+extern __shared__ uint32_t lds_words[];
+
+struct Lds {
+    const uint32_t *lattice;
+    uint32_t *park;   // [slot][sd | prim][point][thread]
+};
+
+__device__ __forceinline__ Lds stage_lds(const SceneView &sc) {
+    for (uint32_t i = threadIdx.x; i < sc.lattice_words; i += blockDim.x) lds_words[i] = sc.lattice[i];
+    __syncthreads();
+    return Lds{ lds_words, lds_words + sc.lattice_words };
+}
+
+__host__ __device__ inline uint32_t lds_bytes(const SceneView &sc) {
+    return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kMaxPts * 256u) * 4u;
+}
+
+// ---- primitive distances (body.cpp:32-35, 41-45, 51-57) --------------------
+
+__device__ __forceinline__ float cross_value(float dx, float dy, float dz) {
+    const float dmin = __builtin_fminf(__builtin_fminf(dx, dy), dz);
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+    return dx + dy + dz - dmin - dmax;
+}
+
+template <uint32_t KIND>
+__device__ __forceinline__ float prim_distance(const Float4 a, const Float4 b, V3 p) {
+    if (KIND == K_SPHERE) {
+        const float dx = a.x - p.x, dy = a.y - p.y, dz = a.z - p.z;
+        return __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - a.w;
+    }
+    const float hy = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.x;
+    const float hz = (KIND == K_BOX_ISO || KIND == K_CROSS_ISO) ? a.w : b.y;
+    const float dx = __builtin_fabsf(p.x - a.x) - a.w;
+    const float dy = __builtin_fabsf(p.y - a.y) - hy;
+    const float dz = __builtin_fabsf(p.z - a.z) - hz;
+    if (KIND == K_BOX || KIND == K_BOX_ISO) return __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+    return cross_value(dx, dy, dz);
+}
+
+// Folds one child value per point into the accumulators (see device_scene.h).
+template <int NP, bool TRACK>
+__device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
+                                           float (&acc)[NP], uint32_t (&accp)[NP]) {
+    const bool neg = (flags & FOLD_NEG) != 0, mx = (flags & FOLD_MAX) != 0;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float c = neg ? -v[n] : v[n];
+        if (TRACK) {
+            // std::min / std::max on Surface: of two equal distances the earlier child survives
+            // (its depth-first index is lower), whatever order the children are folded in
+            const bool take = (mx ? (acc[n] < c) : (c < acc[n])) || (acc[n] == c && vprim[n] < accp[n]);
+            acc[n] = take ? c : acc[n];
+            accp[n] = take ? vprim[n] : accp[n];
+        } else {
+            acc[n] = mx ? __builtin_fmaxf(acc[n], c) : __builtin_fminf(acc[n], c);
+        }
+    }
+}
+
+// One RUN: `count` table rows of one kind, one fold.
+template <uint32_t KIND, bool NEG, bool MAX, int NP, bool TRACK>
+__device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, ConstIndex row_prim, uint32_t first,
+                                         uint32_t count, const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
+    constexpr bool kNeedB = (KIND == K_BOX || KIND == K_CROSS);
+#pragma unroll 4
+    for (uint32_t i = first; i < first + count; ++i) {
+        const RowWords ra = pa[i];
+        const Float4 a = { ra[0], ra[1], ra[2], ra[3] };
+        Float4 b = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (kNeedB) {
+            const RowWords rb = pb[i];
+            b.x = rb[0];
+            b.y = rb[1];
+        }
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            float v = prim_distance<KIND>(a, b, p[n]);
+            if (NEG) v = -v;
+            if (TRACK) {
+                const uint32_t prim = row_prim[i];
+                const bool take = (MAX ? (acc[n] < v) : (v < acc[n])) || (acc[n] == v && prim < accp[n]);
+                acc[n] = take ? v : acc[n];
+                accp[n] = take ? prim : accp[n];
+            } else {
+                acc[n] = MAX ? __builtin_fmaxf(acc[n], v) : __builtin_fminf(acc[n], v);
+            }
+        }
+    }
+}
+
+template <uint32_t KIND, int NP, bool TRACK>
+__device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t flags, uint32_t first, uint32_t count,
+                                              const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP]) {
+    switch (flags & (FOLD_NEG | FOLD_MAX)) {
+    case 0: fold_run<KIND, false, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    case FOLD_NEG: fold_run<KIND, true, false, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    case FOLD_MAX: fold_run<KIND, false, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    default: fold_run<KIND, true, true, NP, TRACK>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, first, count, p, acc, accp); break;
+    }
+}
+
+// ---- LATTICE: a complete Menger lattice of cubic crosses, folded with max(s, -cross) ----------
+//
+// The brute-force fold visits every cross c and keeps max(s, -c(p)), c(p) = dx + dy + dz - min - max
+// with d = |p - centre| - half per axis (body.cpp:51-57).  max() over floats is order-independent,
+// so the result is the largest -c(p) of the lattice, whichever way it is found.  -c(p) can exceed
+// the running value `run` only if the median of (dx, dy, dz) is below -run, i.e. only if at least
+// two of the three axis terms are below tau = -run (+ a bound on the rounding of the five-term
+// sum).  Per level and axis the coordinates are sorted and evenly spaced, so the indices whose axis
+// term is below tau form one short contiguous range around p, found by scanning outwards from an
+// index estimate with the exact axis term.  Only crosses with two axes in range are evaluated --
+// with the exact reference formula, in the reference's operand order -- so the maximum, and
+// therefore every bit of the fold's result, equals the brute-force one.  Levels are visited
+// coarse to fine; a level whose half-width cannot beat `run` ends the walk (-c(p) <= half).
+__device__ __forceinline__ float axis_term(const uint32_t *tab, int i, float p, float h) {
+    return __builtin_fabsf(p - __uint_as_float(tab[i])) - h;
+}
+
+// All i in [0, n) with axis_term(i) < tau: [lo, hi], empty if lo > hi.
+__device__ __forceinline__ void axis_range(const uint32_t *tab, int n, float p, float h, float inv_spacing, float tau,
+                                           int &lo, int &hi) {
+    float u = (p - __uint_as_float(tab[0])) * inv_spacing + 0.5f;   // index estimate; the scan below is exact
+    u = __builtin_fminf(__builtin_fmaxf(u, 0.0f), (float)(n - 1));
+    const int i0 = (int)u;
+    lo = n;
+    hi = -1;
+    for (int i = i0; i >= 0; --i) {
+        if (axis_term(tab, i, p, h) < tau) {
+            lo = i;
+            if (hi < 0) hi = i;
+        } else if (i < i0) {
+            break;
+        }
+    }
+    for (int i = i0 + 1; i < n; ++i) {
+        if (!(axis_term(tab, i, p, h) < tau)) break;
+        hi = i;
+        if (lo > i) lo = i;
+    }
+}
+
+template <bool TRACK, bool COUNT>
+__device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels, uint32_t first_row, V3 p, float &acc,
+                                             uint32_t &acc_prim, uint32_t &n_evals) {
+    const float bound = __builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __uint_as_float(w[2]);
+    const float eps = 2e-6f * bound;   // > 8x the worst rounding of dx + dy + dz - min - max at this magnitude
+    float run = acc;
+    int n = 1;
+    for (uint32_t l = 0; l < levels; ++l, n *= 3) {
+        const float h = __uint_as_float(w[kLatHalf + l]);
+        if (!(run < h * 1.00001f + eps)) break;   // no cross this fine can beat the running value
+        const float tau = eps - run;
+        const float inv = __uint_as_float(w[kLatInvSpacing + l]);
+        const uint32_t *X = w + w[kLatOffset + l];
+        const uint32_t *Y = X + n;
+        const uint32_t *Z = Y + n;
+        const uint32_t *ONES = Z + n;
+        int lox, hix, loy, hiy, loz, hiz;
+        axis_range(X, n, p.x, h, inv, tau, lox, hix);
+        axis_range(Y, n, p.y, h, inv, tau, loy, hiy);
+        axis_range(Z, n, p.z, h, inv, tau, loz, hiz);
+        if (COUNT) n_evals += 3;
+        const bool bx = lox <= hix, by = loy <= hiy, bz = loz <= hiz;
+        if (bx && by) {
+            for (int i = lox; i <= hix; ++i)
+                for (int j = loy; j <= hiy; ++j) {
+                    const uint32_t oi = ONES[i], oj = ONES[j];
+                    if (oi & oj) continue;   // two zero offsets at one subdivision step: no such sub-cube
+                    const float dx = axis_term(X, i, p.x, h), dy = axis_term(Y, j, p.y, h);
+                    for (int k = 0; k < n; ++k) {
+                        const float v = -cross_value(dx, dy, axis_term(Z, k, p.z, h));
+                        run = (ONES[k] & (oi | oj)) ? run : __builtin_fmaxf(run, v);
+                    }
+                    if (COUNT) n_evals += n;
+                }
+        }
+        if (bx && bz) {
+            for (int i = lox; i <= hix; ++i)
+                for (int k = loz; k <= hiz; ++k) {
+                    const uint32_t oi = ONES[i], ok = ONES[k];
+                    if (oi & ok) continue;
+                    const float dx = axis_term(X, i, p.x, h), dz = axis_term(Z, k, p.z, h);
+                    for (int j = 0; j < n; ++j) {
+                        const float v = -cross_value(dx, axis_term(Y, j, p.y, h), dz);
+                        run = (ONES[j] & (oi | ok)) ? run : __builtin_fmaxf(run, v);
+                    }
+                    if (COUNT) n_evals += n;
+                }
+        }
+        if (by && bz) {
+            for (int j = loy; j <= hiy; ++j)
+                for (int k = loz; k <= hiz; ++k) {
+                    const uint32_t oj = ONES[j], ok = ONES[k];
+                    if (oj & ok) continue;
+                    const float dy = axis_term(Y, j, p.y, h), dz = axis_term(Z, k, p.z, h);
+                    for (int i = 0; i < n; ++i) {
+                        const float v = -cross_value(axis_term(X, i, p.x, h), dy, dz);
+                        run = (ONES[i] & (oj | ok)) ? run : __builtin_fmaxf(run, v);
+                    }
+                    if (COUNT) n_evals += n;
+                }
+        }
+    }
+    if (TRACK) acc_prim = (acc < run) ? first_row : acc_prim;   // all crosses of a lattice share one colour
+    acc = run;
+}
+
+template <bool NEG, bool MAX>
+__device__ __forceinline__ float fold_sd(float acc, float v) {
+    return MAX ? __builtin_fmaxf(acc, NEG ? -v : v) : __builtin_fminf(acc, NEG ? -v : v);
+}
+
+template <uint32_t CODE, bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void single_sd(const RecWords &r, const V3 (&p)[NP], float (&acc)[NP]) {
+    const float cx = __uint_as_float(r[0]), cy = __uint_as_float(r[1]), cz = __uint_as_float(r[2]);
+    const float h0 = __uint_as_float(r[3]), h1 = __uint_as_float(r[4]), h2 = __uint_as_float(r[5]);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        float v;
+        if (CODE == REC_SPHERE) {
+            const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
+            v = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
+        } else {
+            const float dx = __builtin_fabsf(p[n].x - cx) - h0;
+            const float dy = __builtin_fabsf(p[n].y - cy) - h1;
+            const float dz = __builtin_fabsf(p[n].z - cz) - h2;
+            v = CODE == REC_CROSS ? cross_value(dx, dy, dz) : __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+        }
+        acc[n] = fold_sd<NEG, MAX>(acc[n], v);
+    }
+}
+
+template <bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void pop_sd(const uint32_t *slot, float (&acc)[NP]) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) acc[n] = fold_sd<NEG, MAX>(__uint_as_float(slot[n * 256]), acc[n]);
+}
+
+#define RM_FOLD_CASES(CODE, CALL)                                   \
+    case CODE: { CALL(false, false); } break;                       \
+    case CODE | FOLD_NEG: { CALL(true, false); } break;             \
+    case CODE | FOLD_MAX: { CALL(false, true); } break;             \
+    case CODE | FOLD_NEG | FOLD_MAX: { CALL(true, true); } break;
+
+__device__ __forceinline__ V3 camera_view(ConstFloats m, V3 v, float w) {
+    return v3(v.x * m[0] + v.y * m[4] + v.z * m[8] + w * m[12], v.x * m[1] + v.y * m[5] + v.z * m[9] + w * m[13],
+              v.x * m[2] + v.y * m[6] + v.z * m[10] + w * m[14]);
+}
+
+__device__ __forceinline__ float lerp1(float u, float v, float t) { return u + t * (v - u); }
+
+struct LaneCounts {
+    uint32_t sdf, steps, rays, evals;
+};
+
+}  // namespace rmdev

@@ -1,0 +1,234 @@
+// trace_kernel.h -- the render kernel body, generic over the scene evaluator `Scene`
+// (InterpretedScene, or the straight-line evaluator generated for one scene):
+//     Scene::sd<NP, COUNT>(sc, lds, points, distances, evals)      distance only
+//     Scene::surface<NP>(sc, lds, points, distances, primitives)   distance + colour-carrying primitive
+#pragma once
+
+#include "device_core.h"
+
+namespace rmdev {
+
+// scene::surface (scene.cpp:34-42) for the lane's two samples in lockstep: advances p[s]
+// along ray[s] while sample s is live; at[s] is the point of its last SDF evaluation (whose
+// Surface the reference returns).
+template <class Scene, int kPts, bool COUNT>
+__device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
+                                      const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], LaneCounts &cnt) {
+    bool done[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        done[s] = !live[s];
+        if (COUNT && live[s]) cnt.rays++;
+    }
+    for (int it = 0; it < fr.iterations; ++it) {
+        bool all_done = true;
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
+        if (all_done) break;
+        float sd[kPts];
+        uint32_t evals[kPts] = {};
+        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, evals);
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) {
+            if (!done[s]) {
+                at[s] = p[s];
+                p[s] = p[s] + ray[s] * sd[s];
+                done[s] = sd[s] < fr.surface_eps;
+                if (COUNT) {
+                    cnt.sdf++;
+                    cnt.steps++;
+                    cnt.evals += evals[s];
+                }
+            }
+        }
+    }
+}
+
+// kPts = 2: block = 32 x 16 sub-samples, each wave a 16 x 8 tile, each lane two horizontally
+// adjacent samples that march in lockstep -- halves the scalar-unit cost per sample, which bounds
+// scenes of few records; a sample that finishes early idles until its partner is done.
+// kPts = 1: block = 16 x 16, wave = 8 x 8, one sample per lane -- for scenes whose cost is in long
+// primitive runs (vector-ALU bound), where idling would cost more than the scalar unit saves.
+// MIN_WAVES: waves per SIMD the register allocation must allow.
+template <class Scene, int kPts, bool COUNT>
+__device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Float4 *__restrict__ samples,
+                                           WorkCounters *__restrict__ counters) {
+    __shared__ unsigned long long block_counts[4];
+    if (COUNT) {
+        if (threadIdx.x < 4) block_counts[threadIdx.x] = 0;
+    }
+    const Lds lds = stage_lds(sc);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t k = fr.kernel;
+    const uint32_t sw = fr.width * k;
+    const uint32_t sh = fr.band_count * fr.band_rows * k;
+    const uint32_t sx0 = blockIdx.x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
+    const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    LaneCounts cnt = { 0, 0, 0, 0 };
+
+    // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
+    const float AR = (float)fr.width / (float)fr.height;
+    const ConstFloats cam = (ConstFloats)sc.camera;   // 16 matrix floats, then the focal length
+    const float w = cam[16];
+    const float h = w / AR;
+    const float s1x = -w / 2, s1y = h / 2;
+    const float s2x = w / 2, s2y = -h / 2;
+    const float psx = 1.0f / (float)fr.width, psy = 1.0f / (float)fr.height;
+    const V3 origin = camera_view(cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
+    const uint32_t ly = sy / k, j = sy - ly * k;   // local pixel row, sub-sample row (inner loop index)
+    const uint32_t band = ly / fr.band_rows;
+    const uint32_t pi = (fr.first_band + band * fr.band_stride) * fr.band_rows + (ly - band * fr.band_rows);
+    const float uv1y = (float)pi * psy, uv2y = (float)(pi + 1u) * psy;
+    const float p1y = lerp1(s1y, s2y, uv1y), p2y = lerp1(s1y, s2y, uv2y);
+    const float uvy = (float)(j + 1u) / (float)k;
+    const float y = lerp1(p1y, p2y, uvy);
+
+    bool stored[kPts], live[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        stored[s] = sx0 + (uint32_t)s < sw && sy < sh;
+        live[s] = stored[s] && pi < fr.height;
+    }
+
+    // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
+    // ray to light l (scene::lighting / scene::shadow, scene.cpp:45-62).  One march instance.
+    V3 hit[kPts], normal[kPts], p[kPts], ray[kPts], at[kPts];
+    float lighting[kPts];
+    uint32_t prim[kPts];
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        hit[s] = origin;
+        normal[s] = v3(0.0f, 0.0f, 0.0f);
+        lighting[s] = 0.0f;
+        prim[s] = kNoPrim;
+    }
+    const float lift = fr.surface_eps + fr.offset_eps;
+#pragma unroll 1
+    for (uint32_t r = 0; r <= sc.n_lights; ++r) {
+        V3 light = v3(0.0f, 0.0f, 0.0f);
+        if (r == 0) {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                const uint32_t sx = sx0 + (uint32_t)s;
+                const uint32_t pj = sx / k, i = sx - pj * k;   // pixel column, sub-sample column (outer loop index)
+                const float uv1x = (float)pj * psx, uv2x = (float)(pj + 1u) * psx;
+                const float p1x = lerp1(s1x, s2x, uv1x), p2x = lerp1(s1x, s2x, uv2x);
+                const float uvx = (float)(i + 1u) / (float)k;
+                const float x = lerp1(p1x, p2x, uvx);
+                p[s] = origin;
+                ray[s] = camera_view(cam, normalize3(v3(x, y, -1.0f)), 0.0f);
+            }
+        } else {
+            const RowWords lp = ((ConstRows)sc.lights)[r - 1];
+            light = v3(lp[0], lp[1], lp[2]);
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                ray[s] = normalize3(light - hit[s]);
+                p[s] = hit[s] + normal[s] * lift;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kPts; ++s) at[s] = p[s];
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, live, cnt);
+        if (r == 0) {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) hit[s] = p[s];
+            // the Surface scene::surface returned: colour of the last evaluation
+            if (fr.iterations > 0) {
+                float sd_unused[kPts];
+                Scene::template surface<kPts>(sc, lds, at, sd_unused, prim);
+            }
+            // scene::grad, scene.cpp:70-89: six taps, one evaluator instance
+            const float hh = 1e-3f;
+            float g[kPts][3] = {};
+#pragma unroll 1
+            for (int axis = 0; axis < 3; ++axis) {
+                const V3 e = v3(axis == 0 ? hh : 0.0f, axis == 1 ? hh : 0.0f, axis == 2 ? hh : 0.0f);
+                float plus[kPts] = {};
+#pragma unroll 1
+                for (int side = 0; side < 2; ++side) {
+                    V3 q[kPts];
+#pragma unroll
+                    for (int s = 0; s < kPts; ++s)
+                        q[s] = side == 0 ? v3(hit[s].x + e.x, hit[s].y + e.y, hit[s].z + e.z)
+                                         : v3(hit[s].x - e.x, hit[s].y - e.y, hit[s].z - e.z);
+                    float sd[kPts];
+                    uint32_t evals[kPts] = {};
+                    Scene::template sd<kPts, COUNT>(sc, lds, q, sd, evals);
+#pragma unroll
+                    for (int s = 0; s < kPts; ++s) {
+                        if (COUNT && live[s]) {
+                            cnt.sdf++;
+                            cnt.evals += evals[s];
+                        }
+                        const float diff = plus[s] - sd[s];
+                        plus[s] = side == 0 ? sd[s] : plus[s];
+                        if (side == 1) {
+                            g[s][0] = axis == 0 ? diff : g[s][0];
+                            g[s][1] = axis == 1 ? diff : g[s][1];
+                            g[s][2] = axis == 2 ? diff : g[s][2];
+                        }
+                    }
+                }
+            }
+            const float two_h = 2 * hh;
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) normal[s] = normalize3(v3(g[s][0] / two_h, g[s][1] / two_h, g[s][2] / two_h));
+        } else {
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) {
+                const bool shadowed = dot3(light - p[s], ray[s]) > 0;
+                if (!shadowed) lighting[s] += dot3(normal[s], ray[s]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int s = 0; s < kPts; ++s) {
+        if (!stored[s]) continue;
+        V3 color = v3(0.0f, 0.0f, 0.0f);
+        if (live[s]) {
+            const float light = __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f);
+            V3 base = v3(0.0f, 0.0f, 0.0f);
+            if (prim[s] != kNoPrim) {
+                const Float4 c = sc.colors[prim[s]];
+                base = v3(c.x, c.y, c.z);
+            }
+            color = v3(light * base.x, light * base.y, light * base.z);
+        }
+        samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
+    }
+
+    if (COUNT) {
+        atomicAdd(&block_counts[0], (unsigned long long)cnt.sdf);
+        atomicAdd(&block_counts[1], (unsigned long long)cnt.steps);
+        atomicAdd(&block_counts[2], (unsigned long long)cnt.rays);
+        atomicAdd(&block_counts[3], (unsigned long long)cnt.evals);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&counters->sdf_calls, block_counts[0]);
+            atomicAdd(&counters->march_steps, block_counts[1]);
+            atomicAdd(&counters->rays, block_counts[2]);
+            atomicAdd(&counters->prim_evals, block_counts[3]);
+        }
+    }
+}
+
+template <class Scene>
+__device__ __forceinline__ void eval_sdf_body(const SceneView &sc, const float *__restrict__ xyz, uint32_t n,
+                                              float *__restrict__ sd, uint32_t *__restrict__ prim) {
+    const Lds lds = stage_lds(sc);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tt = t < n ? t : n - 1;   // every lane walks the scene (nested lists park through LDS)
+    const V3 p[1] = { v3(xyz[3 * tt], xyz[3 * tt + 1], xyz[3 * tt + 2]) };
+    float d[1];
+    uint32_t pr[1];
+    Scene::template surface<1>(sc, lds, p, d, pr);
+    if (t < n) {
+        sd[t] = d[0];
+        prim[t] = pr[0];
+    }
+}
+
+
+}  // namespace rmdev
