@@ -91,6 +91,10 @@ typedef struct rm_counters {
                               11 per sphere, 9 per box, 15 per cross                  */
     double   kernel_ms;    /* device time of the trace kernel(s), HIP events        */
     double   resolve_ms;   /* device time of the resolve kernel                     */
+    double   compile_ms;   /* time rm_set_scene spent compiling the scene's kernels
+                              (0: interpreted mode, or code object found in the cache) */
+    uint32_t compiled_kernel; /* 1 if the last render ran the scene's own kernel      */
+    uint32_t reserved;
 } rm_counters;
 
 typedef struct rm_context rm_context;
@@ -143,6 +147,22 @@ int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_
  */
 typedef enum rm_evaluator { RM_EVAL_EXHAUSTIVE = 0, RM_EVAL_LATTICE = 1 } rm_evaluator;
 int rm_set_evaluator(rm_context *ctx, int evaluator);
+
+/*
+ * Which kernels render the scene.  The reference compiles its compute shader when the program
+ * starts (render::setup::shaders, render.cpp:428-437) and reads the scene from buffers; here
+ *   RM_KERNEL_COMPILED     (default) rm_set_scene generates HIP source for the uploaded scene --
+ *                          every primitive a line of straight-line code with its numbers as
+ *                          literals -- compiles it for gfx950 with hiprtc and renders with that
+ *                          kernel; code objects are cached per process by source text.
+ *                          rm_set_scene fails if the compile fails (no silent fallback);
+ *   RM_KERNEL_INTERPRETED  one ahead-of-time kernel walks the scene's record stream.
+ * Both give bit-identical frames.  Renders with work counting enabled always run the
+ * interpreted kernel (the counts are equal by construction).  Takes effect at the next
+ * rm_set_scene.
+ */
+typedef enum rm_kernel_mode { RM_KERNEL_INTERPRETED = 0, RM_KERNEL_COMPILED = 1 } rm_kernel_mode;
+int rm_set_kernel_mode(rm_context *ctx, int mode);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

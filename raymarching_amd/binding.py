@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -38,7 +38,8 @@ class Rows(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
                 ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("lattice_prims", C.c_uint64),
-                ("flops_per_sdf", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double)]
+                ("flops_per_sdf", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("compile_ms", C.c_double), ("compiled_kernel", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -78,6 +79,7 @@ def lib():
     L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.rm_set_counting.argtypes = [vp, C.c_int]
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
+    L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rm_stream.argtypes = [vp]
     L.rm_stream.restype = vp
@@ -168,7 +170,9 @@ class Renderer:
             lib().rm_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None and _lib is not None:   # module globals are gone at interpreter exit
+            self.close()
 
     def set_params(self, params):
         _check(lib().rm_set_params(self._h, C.byref(params)), "rm_set_params")
@@ -206,6 +210,11 @@ class Renderer:
         prim = np.zeros(len(xyz), np.uint32)
         _check(lib().rm_eval_sdf(self._h, xyz.ctypes.data, len(xyz), sd.ctypes.data, prim.ctypes.data), "rm_eval_sdf")
         return sd, prim
+
+    def set_kernel_mode(self, compiled):
+        """True (default): kernels generated and compiled per scene; False: the record-walking kernel.
+        Takes effect at the next set_scene."""
+        _check(lib().rm_set_kernel_mode(self._h, 1 if compiled else 0), "rm_set_kernel_mode")
 
     def set_evaluator(self, lattice):
         """True: recognise Menger lattices (default); False: visit every primitive.  Applies to the next set_scene."""

@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include "codegen.h"
+#include "jit.h"
 #include "kernels.h"
 #include "program.h"
 #include "scene.h"
@@ -66,6 +68,8 @@ struct rm_context {
 
     bool have_params = false, have_scene = false, counting = false;
     int evaluator = RM_EVAL_LATTICE;
+    int kernel_mode = RM_KERNEL_COMPILED;
+    rmdev::SceneModule module;   // loaded iff the uploaded scene has its own kernels
     rm_params params{};
     rmdev::HostProgram program;
     rmdev::SceneView scene{};
@@ -113,7 +117,10 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->program.run_prims >= 64, ctx->d_samples.ptr, d_cnt, ctx->stream));
+    // work counting runs on the record walker: the counts are properties of the algorithm, equal for both
+    const bool compiled = ctx->module.loaded() && !ctx->counting;
+    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, ctx->d_samples.ptr, ctx->stream));
+    else RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->program.run_prims >= 64, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -127,6 +134,8 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
     ctx->last.prims = ctx->program.n_prims;
     ctx->last.lattice_prims = ctx->program.lattice_prims;
     ctx->last.flops_per_sdf = ctx->program.flops_per_sdf;
+    ctx->last.compile_ms = ctx->module.compile_seconds * 1e3;
+    ctx->last.compiled_kernel = compiled ? 1u : 0u;
     if (ctx->counting) {
         rmdev::WorkCounters h{};
         RM_HIP(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
@@ -177,6 +186,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_recs.release(); ctx->d_pa.release(); ctx->d_pb.release(); ctx->d_colors.release();
     ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
+    ctx->module.unload();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -235,6 +245,16 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.lattice = ctx->d_lattice.ptr;
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;
+    ctx->module.unload();
+    if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
+        const bool wide_runs = ctx->program.run_prims >= 64;
+        const int pts = wide_runs ? 1 : 2, min_waves = wide_runs ? 4 : 8;
+        std::string log;
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, pts, min_waves), pts, ctx->module, log)) {
+            ctx->have_scene = false;
+            return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
+        }
+    }
     ctx->have_scene = true;
     return RM_OK;
 }
@@ -279,7 +299,8 @@ int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_
     RM_HIP(ctx->d_sd.reserve(n));
     RM_HIP(ctx->d_prim.reserve(n));
     RM_HIP(hipMemcpyAsync(ctx->d_points.ptr, host_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    RM_HIP(rmdev::launch_eval_sdf(ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
+    if (ctx->module.loaded()) RM_HIP(rmdev::launch_eval_sdf_module(ctx->module, ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
+    else RM_HIP(rmdev::launch_eval_sdf(ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
     RM_HIP(hipMemcpyAsync(host_sd, ctx->d_sd.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipMemcpyAsync(host_prim, ctx->d_prim.ptr, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
@@ -291,6 +312,13 @@ int rm_set_evaluator(rm_context *ctx, int evaluator) {
     if (evaluator != RM_EVAL_EXHAUSTIVE && evaluator != RM_EVAL_LATTICE)
         return fail(RM_ERR_INVALID, "rm_set_evaluator: unknown evaluator");
     ctx->evaluator = evaluator;
+    return RM_OK;
+}
+
+int rm_set_kernel_mode(rm_context *ctx, int mode) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (mode != RM_KERNEL_INTERPRETED && mode != RM_KERNEL_COMPILED) return fail(RM_ERR_INVALID, "rm_set_kernel_mode: unknown mode");
+    ctx->kernel_mode = mode;
     return RM_OK;
 }
 

@@ -1,0 +1,16 @@
+// codegen.h -- turns a compiled scene (record stream) into HIP source: a `CompiledScene`
+// evaluator whose distance functions are straight-line code with the scene's numbers as
+// literals, plus the extern "C" kernels that use it.
+#pragma once
+
+#include <string>
+
+#include "program.h"
+
+namespace rmdev {
+
+// Kernels emitted: rm_trace (points_per_lane samples per lane, register budget for min_waves waves
+// per SIMD, no work counting) and rm_eval_sdf; signatures as the kernels of kernels.hip.
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves);
+
+}  // namespace rmdev

@@ -251,24 +251,44 @@ __device__ __forceinline__ float fold_sd(float acc, float v) {
     return MAX ? __builtin_fmaxf(acc, NEG ? -v : v) : __builtin_fminf(acc, NEG ? -v : v);
 }
 
+// distance of one SPHERE / BOX / CROSS record's primitive: centre c, half sizes (or radius) h
+template <uint32_t CODE>
+__device__ __forceinline__ float single_distance(V3 p, float cx, float cy, float cz, float h0, float h1, float h2) {
+    if (CODE == REC_SPHERE) {
+        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+        return __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
+    }
+    const float dx = __builtin_fabsf(p.x - cx) - h0;
+    const float dy = __builtin_fabsf(p.y - cy) - h1;
+    const float dz = __builtin_fabsf(p.z - cz) - h2;
+    return CODE == REC_CROSS ? cross_value(dx, dy, dz) : __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+}
+
+template <uint32_t CODE, bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void single_sd(const V3 (&p)[NP], float (&acc)[NP], float cx, float cy, float cz, float h0,
+                                          float h1, float h2) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) acc[n] = fold_sd<NEG, MAX>(acc[n], single_distance<CODE>(p[n], cx, cy, cz, h0, h1, h2));
+}
+
 template <uint32_t CODE, bool NEG, bool MAX, int NP>
 __device__ __forceinline__ void single_sd(const RecWords &r, const V3 (&p)[NP], float (&acc)[NP]) {
-    const float cx = __uint_as_float(r[0]), cy = __uint_as_float(r[1]), cz = __uint_as_float(r[2]);
-    const float h0 = __uint_as_float(r[3]), h1 = __uint_as_float(r[4]), h2 = __uint_as_float(r[5]);
+    single_sd<CODE, NEG, MAX, NP>(p, acc, __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]),
+                                  __uint_as_float(r[3]), __uint_as_float(r[4]), __uint_as_float(r[5]));
+}
+
+// the same with colour tracking and the fold given by flags known at compile time
+template <uint32_t CODE, uint32_t FLAGS, int NP>
+__device__ __forceinline__ void single_surface(const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP], float cx, float cy,
+                                               float cz, float h0, float h1, float h2, uint32_t prim) {
+    float v[NP];
+    uint32_t vp[NP];
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-        float v;
-        if (CODE == REC_SPHERE) {
-            const float dx = cx - p[n].x, dy = cy - p[n].y, dz = cz - p[n].z;
-            v = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) - h0;
-        } else {
-            const float dx = __builtin_fabsf(p[n].x - cx) - h0;
-            const float dy = __builtin_fabsf(p[n].y - cy) - h1;
-            const float dz = __builtin_fabsf(p[n].z - cz) - h2;
-            v = CODE == REC_CROSS ? cross_value(dx, dy, dz) : __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
-        }
-        acc[n] = fold_sd<NEG, MAX>(acc[n], v);
+        v[n] = single_distance<CODE>(p[n], cx, cy, cz, h0, h1, h2);
+        vp[n] = prim;
     }
+    fold_value<NP, true>(FLAGS, v, vp, acc, accp);
 }
 
 template <bool NEG, bool MAX, int NP>

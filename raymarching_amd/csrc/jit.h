@@ -1,0 +1,40 @@
+// jit.h -- run-time compilation of scene-specialised kernels (hiprtc) and their launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "device_scene.h"
+
+namespace rmdev {
+
+struct EmbeddedHeader {
+    const char *name;
+    const char *text;
+};
+extern const EmbeddedHeader kEmbeddedHeaders[];
+extern const unsigned kEmbeddedHeaderCount;
+
+// One loaded code object with the kernels generated for one scene.
+struct SceneModule {
+    hipModule_t module = nullptr;
+    hipFunction_t trace = nullptr;
+    hipFunction_t eval_sdf = nullptr;
+    uint32_t points_per_lane = 0;   // of `trace`
+    double compile_seconds = 0.0;   // 0 when the code came from the process-wide cache
+    bool loaded() const { return module != nullptr; }
+    void unload();
+};
+
+// Compiles `source` (see codegen.cpp) for gfx950 and loads it on the current device.  Code objects
+// are cached per process by source text, so uploading the same scene again costs no compile.
+// Returns false and fills `log` on failure.
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
+
+hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
+                               hipStream_t stream);
+hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
+                                  uint32_t *prim, hipStream_t stream);
+
+}  // namespace rmdev

@@ -31,9 +31,13 @@ def rm():
     return raymarching_amd
 
 
-@pytest.fixture(scope="session")
-def renderer(rm):
+@pytest.fixture(scope="session", params=["compiled", "interpreted"])
+def renderer(rm, request):
+    """One context per kernel mode: kernels generated and compiled for each uploaded scene (the
+    default), and the ahead-of-time kernel that walks the scene's record stream."""
     r = rm.Renderer(0)
+    r.set_kernel_mode(request.param == "compiled")
+    r.kernel_mode = request.param
     yield r
     r.close()
 
