@@ -2,7 +2,7 @@
 """Benchmark of the sphere-tracing hot path: Mrays/s (primary + shadow rays) and frame time.
 
     python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd|closeup6|synthetic]
-                    [--evaluator lattice|exhaustive]
+                    [--evaluator lattice|exhaustive] [--kernel-mode compiled|interpreted]
 
 A step is one frame of the workload.  At N > 1 (one process per GPU, launched by
 torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
@@ -19,6 +19,10 @@ is "strong".  Rank 0 prints ONE JSON line.
                     figure, not a roofline fraction.
     roofline_exhaustive = the same kernel walking every primitive (evaluator "exhaustive"), timed in
                     the same run on a few frames: executed == algorithmic FLOPs there.
+    traffic       = HBM bytes of one trace launch from rocprofv3's TCC counters (2 x FETCH_SIZE + WRITE_SIZE,
+                    the gfx950 correction for wide reads), read from profiles/<round>/traffic.json, which
+                    tools/collect_traffic.py writes from a counter run of this workload (counters cannot be
+                    collected from inside the timed process); null when no such run is on file.
     cpu_baseline  = the CPU oracle (a port of the reference's render::OMP / render::CPU) timed on
                     this host on a stated row sample of the same workload (rank 0, N = 1 only)
 """
@@ -55,6 +59,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS))
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
+    ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
     ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive-leg", action="store_true")
@@ -99,6 +104,18 @@ def executed_flops(c):
     return f_outside * c["sdf_calls"] + 15 * lattice_evals + 7 * c["march_steps"]
 
 
+def recorded_traffic(workload, evaluator, kernel_mode):
+    """HBM bytes per trace launch from the newest committed counter run of this configuration."""
+    base = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(base), reverse=True) if os.path.isdir(base) else []:
+        path = os.path.join(base, rnd, "traffic.json")
+        if os.path.isfile(path):
+            for row in json.load(open(path)):
+                if (row["workload"], row["evaluator"], row["kernel_mode"]) == (workload, evaluator, kernel_mode):
+                    return row["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +135,10 @@ def main():
     r = rm.Renderer(local)
     r.set_params(params)
     r.set_evaluator(a.evaluator == "lattice")
+    r.set_kernel_mode(a.kernel_mode == "compiled")
+    t0 = time.perf_counter()
     r.set_scene(scene)
+    set_scene_s = time.perf_counter() - t0
 
     W, H, k = params.width, params.height, params.kernel
     rays_per_frame = W * H * k * k * (1 + n_lights)
@@ -133,7 +153,7 @@ def main():
         return sharding.gather_frame(shard, H, a.band_rows, world, rank, gathered)
 
     # ---- work count of this rank's share (instrumented kernel, outside the timed region)
-    r.set_counting(True)
+    r.set_counting(True)   # (counted renders run the record-walking kernel: same algorithm, same counts)
     frame()
     cnt = r.counters()
     r.set_counting(False)
@@ -181,7 +201,7 @@ def main():
             ms.append(r.counters()["kernel_ms"])
         ex_ms = sum(ms) / len(ms)
         achieved = local_algo / (ex_ms * 1e-3) / 1e12
-        exhaustive = {"bound": "valu_fp32", "kernel": "trace_kernel<1,4> (one sample per lane, every primitive visited)",
+        exhaustive = {"bound": "valu_fp32", "kernel": "one sample per lane, every primitive visited (" + a.kernel_mode + ")",
                       "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(ex_ms, 4),
                       "mrays_per_s": round(rays_per_frame / world / ex_ms / 1e3, 2) if world == 1 else None}
@@ -193,17 +213,19 @@ def main():
         value = rays_per_frame * a.steps / elapsed / 1e6
         # dominant kernel: the trace kernel of rank 0, its own executed flops over its own duration
         achieved = local_exec / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_src = recorded_traffic(a.workload, a.evaluator, a.kernel_mode) if world == 1 else (None, None)
         line = {
             "metric": "Mrays/s (primary+shadow), default scene", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": scene_name, "width": W, "height": H, "ssaa_kernel": k,
                        "lights": n_lights, "primitives": cnt["prims"], "rays_per_frame": rays_per_frame,
-                       "evaluator": a.evaluator,
+                       "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
+                       "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
                        "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows}, cyclic over {world} ranks, RCCL gather of RGBA8 to rank 0"},
             "roofline": {
-                "bound": "valu_fp32", "kernel": "trace_kernel", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": round(kernel_ms, 4), "flops": "executed (counted primitive evaluations)",
                 "executed_flops_per_frame": int(total_exec), "sdf_calls_per_frame": int(total_sdf),
                 "prim_evals_per_sdf_call": round(cnt["prim_evals"] / max(1, cnt["sdf_calls"]), 2),

@@ -95,6 +95,9 @@ typedef struct rm_counters {
                               (0: interpreted mode, or code object found in the cache) */
     uint32_t compiled_kernel; /* 1 if the last render ran the scene's own kernel      */
     uint32_t reserved;
+    uint64_t march_slots;  /* march-loop iterations x samples of the lanes that sat through them,
+                              live or idle: march_steps / march_slots = lane utilisation of
+                              the sphere-tracing loop                                   */
 } rm_counters;
 
 typedef struct rm_context rm_context;

@@ -143,6 +143,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         ctx->last.march_steps = h.march_steps;
         ctx->last.rays = h.rays;
         ctx->last.prim_evals = h.prim_evals;
+        ctx->last.march_slots = h.march_slots;
     }
     return RM_OK;
 }
@@ -247,8 +248,10 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.camera = ctx->d_camera.ptr;
     ctx->module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
-        const bool wide_runs = ctx->program.run_prims >= 64;
-        const int pts = wide_runs ? 1 : 2, min_waves = wide_runs ? 4 : 8;
+        // One sample per lane: with the scene in the instruction stream there is no per-record scalar
+        // work left to share between two samples, and a second sample would double the divergent
+        // lattice walks.  128 registers per lane (4 waves per SIMD) avoid all spills.
+        const int pts = 1, min_waves = 4;
         std::string log;
         if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, pts, min_waves), pts, ctx->module, log)) {
             ctx->have_scene = false;

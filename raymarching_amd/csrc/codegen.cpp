@@ -9,9 +9,11 @@
 // the record walker (interp_scene.h), so results are bit-identical to it.
 #include "codegen.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace rmdev {
 
@@ -47,74 +49,190 @@ const char *kind_name(uint32_t kind) {
 
 std::string tf(bool b) { return b ? "true" : "false"; }
 
-// body of sd() (track = false) or surface() (track = true)
-std::string emit_body(const HostProgram &prog, bool track) {
+// ---- the record stream as a tree (children of a list may be emitted in any order: min and max
+// are exact selections, and the colour-tracking walk breaks ties by depth-first index) ------------
+
+struct Item {
+    uint32_t rec = 0;              // leaf: its record; list: its PUSH record
+    uint32_t pop = 0;              // list: its POP record
+    bool is_list = false;
+    std::vector<Item> children;    // list only
+};
+
+// parses recs[i..] up to the END or the POP that closes the current list; returns the index after it
+uint32_t parse_children(const std::vector<Rec> &recs, uint32_t i, std::vector<Item> &out) {
+    while (i < recs.size()) {
+        const uint32_t code = recs[i].flags & 15u;
+        if (code == REC_END || code == REC_POP) return i;
+        Item it;
+        it.rec = i;
+        if (code == REC_PUSH) {
+            it.is_list = true;
+            it.pop = parse_children(recs, i + 1, it.children);
+            i = it.pop + 1;
+        } else {
+            i++;
+        }
+        out.push_back(std::move(it));
+    }
+    return i;
+}
+
+struct Emitter {
+    const HostProgram &prog;
+    bool track;
     std::string s;
-    char buf[512];
-    uint32_t depth = 0;
     unsigned long long counted = 0;   // primitive evaluations per call outside lattices
-    auto acc = [&](uint32_t d) { return "a" + std::to_string(d); };
-    auto accp = [&](uint32_t d) { return "q" + std::to_string(d); };
-    auto declare = [&](uint32_t d, float identity) {
+    char buf[640];
+
+    std::string acc(uint32_t d) const { return "a" + std::to_string(d); }
+    std::string accp(uint32_t d) const { return track ? "q" + std::to_string(d) : "no_prim"; }
+
+    void declare(uint32_t d, float identity) {
         s += "    float " + acc(d) + "[NP];\n";
         if (track) s += "    uint32_t " + accp(d) + "[NP];\n";
         s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { " + acc(d) + "[n] = " + lit(identity) + ";" +
              (track ? " " + accp(d) + "[n] = kNoPrim;" : "") + " }\n";
-    };
-    declare(0, prog.root_identity);
-    if (!track) s += "    uint32_t no_prim[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;\n";
-    for (const Rec &r : prog.recs) {
+    }
+
+    std::string centre_and_half(const Rec &r) const {
+        return lit(as_float(r.a[0])) + ", " + lit(as_float(r.a[1])) + ", " + lit(as_float(r.a[2])) + ", " + lit(as_float(r.h[0])) +
+               ", " + lit(as_float(r.h[1])) + ", " + lit(as_float(r.h[2]));
+    }
+
+    void leaf(const Rec &r, uint32_t depth) {
         const uint32_t code = r.flags & 15u;
         const bool neg = (r.flags & FOLD_NEG) != 0, mx = (r.flags & FOLD_MAX) != 0;
-        if (code == REC_END) break;
         if (code <= REC_CROSS) {
-            std::string args = lit(as_float(r.a[0])) + ", " + lit(as_float(r.a[1])) + ", " + lit(as_float(r.a[2])) + ", " +
-                               lit(as_float(r.h[0])) + ", " + lit(as_float(r.h[1])) + ", " + lit(as_float(r.h[2]));
             if (track) {
                 std::snprintf(buf, sizeof buf, "    single_surface<%s, %uu, NP>(p, %s, %s, %s, %uu);\n", code_name(code),
-                              r.flags & (FOLD_NEG | FOLD_MAX), acc(depth).c_str(), accp(depth).c_str(), args.c_str(), r.prim);
+                              r.flags & (FOLD_NEG | FOLD_MAX), acc(depth).c_str(), accp(depth).c_str(), centre_and_half(r).c_str(), r.prim);
             } else {
                 std::snprintf(buf, sizeof buf, "    single_sd<%s, %s, %s, NP>(p, %s, %s);\n", code_name(code), tf(neg).c_str(),
-                              tf(mx).c_str(), acc(depth).c_str(), args.c_str());
+                              tf(mx).c_str(), acc(depth).c_str(), centre_and_half(r).c_str());
             }
-            s += buf;
             counted++;
         } else if (code == REC_RUN) {
             std::snprintf(buf, sizeof buf,
                           "    fold_run<%s, %s, %s, NP, %s>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, %uu, %uu, p, %s, %s);\n",
                           kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), tf(track).c_str(), r.a[0], r.a[1], acc(depth).c_str(),
-                          track ? accp(depth).c_str() : "no_prim");
-            s += buf;
+                          accp(depth).c_str());
             counted += r.a[1];
-        } else if (code == REC_LATTICE) {
+        } else {   // REC_LATTICE
             std::snprintf(buf, sizeof buf,
                           "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<%s, %s>(lds.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], n_evals[n]);\n",
-                          tf(track).c_str(), track ? "false" : "COUNT", r.a[1], r.a[0], r.prim, acc(depth).c_str(),
-                          track ? accp(depth).c_str() : "no_prim");
-            s += buf;
-        } else if (code == REC_PUSH) {
-            s += "    {\n";
-            depth++;
-            declare(depth, as_float(r.a[1]));
-        } else {   // REC_POP
-            if (track) {
-                std::snprintf(buf, sizeof buf, "    fold_value<NP, true>(%uu, %s, %s, %s, %s);\n", r.flags & (FOLD_NEG | FOLD_MAX),
-                              acc(depth).c_str(), accp(depth).c_str(), acc(depth - 1).c_str(), accp(depth - 1).c_str());
-            } else {
-                std::snprintf(buf, sizeof buf, "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) %s[n] = fold_sd<%s, %s>(%s[n], %s[n]);\n",
-                              acc(depth - 1).c_str(), tf(neg).c_str(), tf(mx).c_str(), acc(depth - 1).c_str(), acc(depth).c_str());
-            }
-            s += buf;
-            s += "    }\n";
-            depth--;
+                          tf(track).c_str(), track ? "false" : "COUNT", r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
         }
-    }
-    if (!track) {
-        std::snprintf(buf, sizeof buf, "    if (COUNT) { _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) n_evals[n] += %lluu; }\n", counted);
         s += buf;
     }
-    s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : "") + " }\n";
-    return s;
+
+    // cost rank of a child in the distance-only walk: cheap bounds first, lists last
+    static int rank(const std::vector<Rec> &recs, const Item &it) {
+        if (it.is_list) {
+            if (it.children.size() == 1 && !it.children[0].is_list && (recs[it.children[0].rec].flags & 15u) <= REC_CROSS) return rank(recs, it.children[0]);
+            return 5;
+        }
+        switch (recs[it.rec].flags & 15u) {
+        case REC_BOX: return 0;
+        case REC_CROSS: return 1;
+        case REC_SPHERE: return 2;
+        case REC_RUN: return 3;
+        default: return 4;
+        }
+    }
+
+    void children(const std::vector<Item> &items, uint32_t depth) {
+        std::vector<const Item *> order;
+        for (const Item &it : items) order.push_back(&it);
+        if (!track) std::stable_sort(order.begin(), order.end(), [&](const Item *x, const Item *y) { return rank(prog.recs, *x) < rank(prog.recs, *y); });
+        for (const Item *it : order) {
+            if (!it->is_list) {
+                leaf(prog.recs[it->rec], depth);
+            } else if (it->children.size() == 1 && !it->children[0].is_list && (prog.recs[it->children[0].rec].flags & 15u) <= REC_CROSS) {
+                // a list of one primitive is that primitive, negated if the list negates its first child,
+                // folded the way the list is folded into its parent
+                Rec r = prog.recs[it->children[0].rec];
+                const uint32_t pop = prog.recs[it->pop].flags;
+                r.flags = (r.flags & 15u) | (((r.flags ^ pop) & FOLD_NEG)) | (pop & FOLD_MAX);
+                leaf(r, depth);
+            } else {
+                list(*it, depth);
+            }
+        }
+    }
+
+    // A nested list.  In the distance-only walk the list is skipped when one of its children
+    // proves that its value cannot change the parent's accumulator: a list folded with max is at
+    // least, one folded with min at most, any single child's contribution c, so if folding c
+    // alone into the parent would leave the parent unchanged, so does folding the list (when the
+    // directions agree: list-max with a parent that keeps small values, and so on).  The test
+    // is made per wave; if any lane needs the list, all lanes evaluate it, exactly.
+    void list(const Item &it, uint32_t depth) {
+        const Rec &push = prog.recs[it.rec], &pop = prog.recs[it.pop];
+        const float identity = as_float(push.a[1]);
+        const bool list_max = identity < 0;   // -inf: folded with max
+        const bool pop_neg = (pop.flags & FOLD_NEG) != 0, pop_max = (pop.flags & FOLD_MAX) != 0;
+        const Item *bound = nullptr;
+        if (!track && list_max == (pop_neg == pop_max)) {
+            for (const Item &c : it.children) {
+                if (c.is_list) continue;
+                const uint32_t code = prog.recs[c.rec].flags & 15u;
+                if (code > REC_CROSS) continue;
+                if (!bound || rank(prog.recs, c) < rank(prog.recs, *bound)) bound = &c;
+            }
+        }
+        const uint32_t d = depth + 1;
+        s += "    {\n";
+        if (bound) {
+            const Rec &b = prog.recs[bound->rec];
+            const uint32_t code = b.flags & 15u;
+            const bool neg = ((b.flags & FOLD_NEG) != 0) != pop_neg;   // sign of the child's value as the parent sees it
+            s += "    bool need = false;\n";
+            if (code == REC_SPHERE) {
+                std::snprintf(buf, sizeof buf,
+                              "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) need = need || !sphere_cannot_change<%s, %s>(%s[n], "
+                              "sphere_d2(p[n], %s, %s, %s), %s);\n",
+                              tf(neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), lit(as_float(b.a[0])).c_str(),
+                              lit(as_float(b.a[1])).c_str(), lit(as_float(b.a[2])).c_str(), lit(as_float(b.h[0])).c_str());
+            } else {
+                std::snprintf(buf, sizeof buf,
+                              "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) need = need || value_can_change<%s, %s>(%s[n], "
+                              "single_distance<%s>(p[n], %s));\n",
+                              tf(neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), code_name(code), centre_and_half(b).c_str());
+            }
+            s += buf;
+            s += "    if (__builtin_amdgcn_ballot_w64(need) != 0) {\n    keep_in_branch();\n";
+        }
+        declare(d, identity);
+        children(it.children, d);
+        if (track) {
+            std::snprintf(buf, sizeof buf, "    fold_value<NP, true>(%uu, %s, %s, %s, %s);\n", pop.flags & (FOLD_NEG | FOLD_MAX), acc(d).c_str(),
+                          accp(d).c_str(), acc(depth).c_str(), accp(depth).c_str());
+        } else {
+            std::snprintf(buf, sizeof buf, "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) %s[n] = fold_sd<%s, %s>(%s[n], %s[n]);\n",
+                          acc(depth).c_str(), tf(pop_neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), acc(d).c_str());
+        }
+        s += buf;
+        if (bound) s += "    }\n";
+        s += "    }\n";
+    }
+};
+
+// body of sd() (track = false) or surface() (track = true)
+std::string emit_body(const HostProgram &prog, bool track) {
+    Emitter e{ prog, track };
+    std::vector<Item> top;
+    parse_children(prog.recs, 0, top);
+    e.declare(0, prog.root_identity);
+    if (!track) e.s += "    uint32_t no_prim[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;\n";
+    e.children(top, 0);
+    char buf[256];
+    if (!track) {
+        std::snprintf(buf, sizeof buf, "    if (COUNT) { _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) n_evals[n] += %lluu; }\n", e.counted);
+        e.s += buf;
+    }
+    e.s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : "") + " }\n";
+    return e.s;
 }
 
 }  // namespace

@@ -78,6 +78,57 @@ __device__ __forceinline__ float prim_distance(const Float4 a, const Float4 b, V
     return cross_value(dx, dy, dz);
 }
 
+template <bool NEG, bool MAX>
+__device__ __forceinline__ float fold_sd(float acc, float v) {
+    return MAX ? __builtin_fmaxf(acc, NEG ? -v : v) : __builtin_fminf(acc, NEG ? -v : v);
+}
+
+// True if folding the sphere value v = sqrt(d2) - r into `acc` cannot change `acc`, decided without
+// the square root (correctly rounded, it costs about as much as the rest of the sphere twice over).
+// With S = sqrt(d2) and T = r - acc (negated folds) or acc + r:
+//   min(acc, v), max(acc, -v)   change acc only if S < T:  no change if T < 0 or d2 > T^2 (1 + 1e-5)
+//   min(acc, -v), max(acc, v)   change acc only if S > T:  no change if T > 0 and d2 (1 + 1e-5) < T^2
+// The 1e-5 margin covers the roundings of T, T^2, d2's factor, S and S - r (each below 2^-23
+// relative), the 1e-30 the loss of precision of T^2 or d2 near underflow; NaNs, infinite T^2 and
+// everything near the boundary fail the test and take the exact path, so the fold's result is that
+// of the plain formula bit for bit.
+template <bool NEG, bool MAX>
+__device__ __forceinline__ bool sphere_cannot_change(float acc, float d2, float r) {
+    const float t = NEG ? r - acc : acc + r;
+    const float t2 = t * t;
+    if (NEG == MAX) return t < 0.0f || d2 > __builtin_fmaf(t2, 1.00001f, 1e-30f);
+    return t > 0.0f && __builtin_fmaf(d2, 1.00001f, 1e-30f) < t2;
+}
+
+__device__ __forceinline__ float sphere_d2(V3 p, float cx, float cy, float cz) {
+    const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// True unless folding the child value v into `acc` provably leaves `acc` as it is (NaNs count
+// as "can change").
+template <bool NEG, bool MAX>
+__device__ __forceinline__ bool value_can_change(float acc, float v) {
+    const float c = NEG ? -v : v;
+    return MAX ? !(c <= acc) : !(c >= acc);
+}
+
+// Marks a branch whose body must stay in the branch (stops the compiler from turning a cheap-looking
+// body into unconditional code with selects).
+__device__ __forceinline__ void keep_in_branch() { asm volatile(""); }
+
+template <bool NEG, bool MAX>
+__device__ __forceinline__ float fold_sphere(float acc, V3 p, float cx, float cy, float cz, float r) {
+    // One wave-uniform branch: taken, every lane folds (the fold is exact for all of them).  The
+    // empty asm keeps the compiler from hoisting the square root out of the branch.
+    float d2 = sphere_d2(p, cx, cy, cz);
+    if (__builtin_amdgcn_ballot_w64(!sphere_cannot_change<NEG, MAX>(acc, d2, r)) != 0) {
+        asm volatile("" : "+v"(d2));
+        acc = fold_sd<NEG, MAX>(acc, __builtin_sqrtf(d2) - r);
+    }
+    return acc;
+}
+
 // Folds one child value per point into the accumulators (see device_scene.h).
 template <int NP, bool TRACK>
 __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
@@ -115,6 +166,10 @@ __device__ __forceinline__ void fold_run(ConstRows pa, ConstRows pb, ConstIndex 
         }
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
+            if (KIND == K_SPHERE && !TRACK) {
+                acc[n] = fold_sphere<NEG, MAX>(acc[n], p[n], a.x, a.y, a.z, a.w);
+                continue;
+            }
             float v = prim_distance<KIND>(a, b, p[n]);
             if (NEG) v = -v;
             if (TRACK) {
@@ -246,11 +301,6 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
     acc = run;
 }
 
-template <bool NEG, bool MAX>
-__device__ __forceinline__ float fold_sd(float acc, float v) {
-    return MAX ? __builtin_fmaxf(acc, NEG ? -v : v) : __builtin_fminf(acc, NEG ? -v : v);
-}
-
 // distance of one SPHERE / BOX / CROSS record's primitive: centre c, half sizes (or radius) h
 template <uint32_t CODE>
 __device__ __forceinline__ float single_distance(V3 p, float cx, float cy, float cz, float h0, float h1, float h2) {
@@ -268,7 +318,10 @@ template <uint32_t CODE, bool NEG, bool MAX, int NP>
 __device__ __forceinline__ void single_sd(const V3 (&p)[NP], float (&acc)[NP], float cx, float cy, float cz, float h0,
                                           float h1, float h2) {
 #pragma unroll
-    for (int n = 0; n < NP; ++n) acc[n] = fold_sd<NEG, MAX>(acc[n], single_distance<CODE>(p[n], cx, cy, cz, h0, h1, h2));
+    for (int n = 0; n < NP; ++n) {
+        if (CODE == REC_SPHERE) acc[n] = fold_sphere<NEG, MAX>(acc[n], p[n], cx, cy, cz, h0);
+        else acc[n] = fold_sd<NEG, MAX>(acc[n], single_distance<CODE>(p[n], cx, cy, cz, h0, h1, h2));
+    }
 }
 
 template <uint32_t CODE, bool NEG, bool MAX, int NP>
@@ -311,7 +364,7 @@ __device__ __forceinline__ V3 camera_view(ConstFloats m, V3 v, float w) {
 __device__ __forceinline__ float lerp1(float u, float v, float t) { return u + t * (v - u); }
 
 struct LaneCounts {
-    uint32_t sdf, steps, rays, evals;
+    uint32_t sdf, steps, rays, evals, slots;
 };
 
 }  // namespace rmdev

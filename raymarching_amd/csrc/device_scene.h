@@ -116,6 +116,7 @@ struct WorkCounters {
     unsigned long long march_steps;
     unsigned long long rays;
     unsigned long long prim_evals;   // primitive distance evaluations (incl. lattice axis scans, 3 per level)
+    unsigned long long march_slots;  // march-loop iterations x samples of the lanes that sat through them (live or idle)
 };
 
 }  // namespace rmdev

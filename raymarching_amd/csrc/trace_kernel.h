@@ -28,6 +28,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         float sd[kPts];
         uint32_t evals[kPts] = {};
         Scene::template sd<kPts, COUNT>(sc, lds, p, sd, evals);
+        if (COUNT) cnt.slots += kPts;
 #pragma unroll
         for (int s = 0; s < kPts; ++s) {
             if (!done[s]) {
@@ -53,9 +54,9 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Float4 *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
-    __shared__ unsigned long long block_counts[4];
+    __shared__ unsigned long long block_counts[5];
     if (COUNT) {
-        if (threadIdx.x < 4) block_counts[threadIdx.x] = 0;
+        if (threadIdx.x < 5) block_counts[threadIdx.x] = 0;
     }
     const Lds lds = stage_lds(sc);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t sh = fr.band_count * fr.band_rows * k;
     const uint32_t sx0 = blockIdx.x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
     const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    LaneCounts cnt = { 0, 0, 0, 0 };
+    LaneCounts cnt = { 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
     const float AR = (float)fr.width / (float)fr.height;
@@ -204,12 +205,14 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         atomicAdd(&block_counts[1], (unsigned long long)cnt.steps);
         atomicAdd(&block_counts[2], (unsigned long long)cnt.rays);
         atomicAdd(&block_counts[3], (unsigned long long)cnt.evals);
+        atomicAdd(&block_counts[4], (unsigned long long)cnt.slots);
         __syncthreads();
         if (threadIdx.x == 0) {
             atomicAdd(&counters->sdf_calls, block_counts[0]);
             atomicAdd(&counters->march_steps, block_counts[1]);
             atomicAdd(&counters->rays, block_counts[2]);
             atomicAdd(&counters->prim_evals, block_counts[3]);
+            atomicAdd(&counters->march_slots, block_counts[4]);
         }
     }
 }

@@ -20,5 +20,6 @@ for path in sys.argv[1:]:
         r.render_rgba8()
         ms.append(r.counters()["kernel_ms"])
     print(f"{os.path.basename(path):20s} min {min(ms):.3f} ms  sdf_calls {c['sdf_calls']}  evals/call {c['prim_evals'] / max(1, c['sdf_calls']):.2f}"
-          f"  ns/1000 calls {min(ms) * 1e6 / c['sdf_calls'] * 1000:.1f}", flush=True)
+          f"  ns/1000 calls {min(ms) * 1e6 / c['sdf_calls'] * 1000:.1f}  march lane utilisation {c['march_steps'] / max(1, c['march_slots']):.3f}"
+          f"  steps/ray {c['march_steps'] / max(1, c['rays']):.1f}", flush=True)
 r.close()
