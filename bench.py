@@ -11,14 +11,15 @@ renders its bands into device memory and the RGBA8 bands are gathered to rank 0 
 is "strong".  Rank 0 prints ONE JSON line.
 
     value         = frames * W*H*k*k*(1+L) rays / wall time (max over ranks), in Mrays/s
-    roofline      = FLOPs the trace kernel EXECUTED for the frame (counted primitive evaluations x
-                    FLOPs per primitive + 7 per march step) / its HIP-event duration, against the
-                    fp32 vector peak.  With the default lattice evaluator most primitives are never
-                    visited; `brute_force_equivalent` gives the reference algorithm's FLOPs (counted
+    roofline      = FLOPs the trace kernel EXECUTED for the frame (its counting variant's tally of the
+                    primitive evaluations it executed x FLOPs per primitive + 7 per march step) / its
+                    HIP-event duration, against the fp32 vector peak.  The default kernels never visit most
+                    primitives (lattice evaluator, lists skipped by a bounding child); `brute_force_equivalent` gives the reference algorithm's FLOPs (counted
                     scene-SDF calls x FLOPs of one exhaustive call) over the same time, a speed-up
                     figure, not a roofline fraction.
-    roofline_exhaustive = the same kernel walking every primitive (evaluator "exhaustive"), timed in
-                    the same run on a few frames: executed == algorithmic FLOPs there.
+    roofline_exhaustive = the reference's algorithm as it stands (every primitive at every SDF call) on the
+                    record-walking kernel, timed in the same run on a few frames: executed == algorithmic
+                    FLOPs there.
     traffic       = HBM bytes of one trace launch from rocprofv3's TCC counters (2 x FETCH_SIZE + WRITE_SIZE,
                     the gfx950 correction for wide reads), read from profiles/<round>/traffic.json, which
                     tools/collect_traffic.py writes from a counter run of this workload (counters cannot be
@@ -96,12 +97,10 @@ def cpu_baseline(scene_file, kw):
 
 
 def executed_flops(c):
-    """FLOPs the trace kernel executed for the counted frame: primitives outside lattices are
-    evaluated at every SDF call, lattice crosses (15 FLOPs) only when visited; 7 per march step."""
-    outside = c["prims"] - c["lattice_prims"]
-    f_outside = c["flops_per_sdf"] - 15 * c["lattice_prims"]
-    lattice_evals = c["prim_evals"] - outside * c["sdf_calls"]
-    return f_outside * c["sdf_calls"] + 15 * lattice_evals + 7 * c["march_steps"]
+    """FLOPs the trace kernel executed for the counted frame: the kernel's own tally of the primitive
+    evaluations it executed (11 per sphere, 9 per box, 15 per cross; lists skipped by a bound and lattice
+    crosses never visited are not in it) + 7 per march step."""
+    return c["flops_executed"] + 7 * c["march_steps"]
 
 
 def recorded_traffic(workload, evaluator, kernel_mode):
@@ -153,7 +152,7 @@ def main():
         return sharding.gather_frame(shard, H, a.band_rows, world, rank, gathered)
 
     # ---- work count of this rank's share (instrumented kernel, outside the timed region)
-    r.set_counting(True)   # (counted renders run the record-walking kernel: same algorithm, same counts)
+    r.set_counting(True)
     frame()
     cnt = r.counters()
     r.set_counting(False)
@@ -188,10 +187,12 @@ def main():
     else:
         kernel_ms_max, total_exec, total_algo, total_sdf = kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])
 
-    # ---- the same kernel with every primitive visited (rank 0's share, a few frames)
+    # ---- the reference's algorithm as it stands -- every primitive evaluated at every SDF call -- on the
+    # record-walking kernel (rank 0's share, a few frames): executed == algorithmic FLOPs there
     exhaustive = None
-    if a.evaluator == "lattice" and not a.no_exhaustive_leg and cnt["lattice_prims"] and cnt["prims"] <= 20000:
+    if not a.no_exhaustive_leg and cnt["prims"] <= 20000:
         r.set_evaluator(False)
+        r.set_kernel_mode(False)
         r.set_scene(scene)
         for _ in range(2):
             r.render_device(rows, None, shard.data_ptr())
@@ -201,11 +202,12 @@ def main():
             ms.append(r.counters()["kernel_ms"])
         ex_ms = sum(ms) / len(ms)
         achieved = local_algo / (ex_ms * 1e-3) / 1e12
-        exhaustive = {"bound": "valu_fp32", "kernel": "one sample per lane, every primitive visited (" + a.kernel_mode + ")",
+        exhaustive = {"bound": "valu_fp32", "kernel": "trace_kernel (record walker), every primitive visited at every SDF call",
                       "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(ex_ms, 4),
                       "mrays_per_s": round(rays_per_frame / world / ex_ms / 1e3, 2) if world == 1 else None}
-        r.set_evaluator(True)
+        r.set_evaluator(a.evaluator == "lattice")
+        r.set_kernel_mode(a.kernel_mode == "compiled")
         r.set_scene(scene)
 
     if rank == 0:

@@ -98,6 +98,9 @@ typedef struct rm_counters {
     uint64_t march_slots;  /* march-loop iterations x samples of the lanes that sat through them,
                               live or idle: march_steps / march_slots = lane utilisation of
                               the sphere-tracing loop                                   */
+    uint64_t flops_executed; /* algorithmic FLOPs of the primitive evaluations the kernel executed
+                              (11 per sphere, 9 per box, 15 per cross; evaluations skipped by a
+                              bound or a lattice are not counted), march steps excluded  */
 } rm_counters;
 
 typedef struct rm_context rm_context;
@@ -160,9 +163,10 @@ int rm_set_evaluator(rm_context *ctx, int evaluator);
  *                          kernel; code objects are cached per process by source text.
  *                          rm_set_scene fails if the compile fails (no silent fallback);
  *   RM_KERNEL_INTERPRETED  one ahead-of-time kernel walks the scene's record stream.
- * Both give bit-identical frames.  Renders with work counting enabled always run the
- * interpreted kernel (the counts are equal by construction).  Takes effect at the next
- * rm_set_scene.
+ * Both give bit-identical frames.  With work counting enabled each mode runs its own counting
+ * variant (compiled lazily at the first counted render), so prim_evals and flops_executed are
+ * those of the mode: the compiled kernels skip work the interpreted one does.  Takes effect
+ * at the next rm_set_scene.
  */
 typedef enum rm_kernel_mode { RM_KERNEL_INTERPRETED = 0, RM_KERNEL_COMPILED = 1 } rm_kernel_mode;
 int rm_set_kernel_mode(rm_context *ctx, int mode);

@@ -70,6 +70,7 @@ struct rm_context {
     int evaluator = RM_EVAL_LATTICE;
     int kernel_mode = RM_KERNEL_COMPILED;
     rmdev::SceneModule module;   // loaded iff the uploaded scene has its own kernels
+    rmdev::SceneModule counting_module;   // the same with work counting, compiled at the first counted render
     rm_params params{};
     rmdev::HostProgram program;
     rmdev::SceneView scene{};
@@ -86,6 +87,12 @@ struct rm_context {
 };
 
 namespace {
+
+// Launch shape of the compiled kernels.  One sample per lane: with the scene in the instruction
+// stream there is no per-record scalar work left to share between two samples, and a second
+// sample would double the divergent lattice walks.  128 registers per lane (4 waves per SIMD)
+// avoid all spills.
+constexpr int kCompiledPts = 1, kCompiledWaves = 4;
 
 int check_ready(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
@@ -117,9 +124,14 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    // work counting runs on the record walker: the counts are properties of the algorithm, equal for both
-    const bool compiled = ctx->module.loaded() && !ctx->counting;
-    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, ctx->d_samples.ptr, ctx->stream));
+    const bool compiled = ctx->module.loaded();
+    if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
+        std::string log;
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
+                                         ctx->counting_module, log))
+            return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
+    }
+    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->program.run_prims >= 64, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
@@ -144,6 +156,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         ctx->last.rays = h.rays;
         ctx->last.prim_evals = h.prim_evals;
         ctx->last.march_slots = h.march_slots;
+        ctx->last.flops_executed = h.flops;
     }
     return RM_OK;
 }
@@ -188,6 +201,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_lights.release(); ctx->d_samples.release(); ctx->d_frame_f32.release();
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
     ctx->module.unload();
+    ctx->counting_module.unload();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -247,13 +261,10 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;
     ctx->module.unload();
+    ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
-        // One sample per lane: with the scene in the instruction stream there is no per-record scalar
-        // work left to share between two samples, and a second sample would double the divergent
-        // lattice walks.  128 registers per lane (4 waves per SIMD) avoid all spills.
-        const int pts = 1, min_waves = 4;
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, pts, min_waves), pts, ctx->module, log)) {
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false), kCompiledPts, ctx->module, log)) {
             ctx->have_scene = false;
             return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
         }

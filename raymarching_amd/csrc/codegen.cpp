@@ -82,8 +82,18 @@ struct Emitter {
     const HostProgram &prog;
     bool track;
     std::string s;
-    unsigned long long counted = 0;   // primitive evaluations per call outside lattices
+    unsigned evals = 0, flops = 0;    // work of the leaves emitted into the current block, not yet booked
     char buf[640];
+
+    // books the block's pending work (the counting variant only; `COUNT` is a template parameter)
+    void book() {
+        if (!track && evals) {
+            std::snprintf(buf, sizeof buf, "    if (COUNT) { _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { work[n].evals += %uu; work[n].flops += %uu; } }\n",
+                          evals, flops);
+            s += buf;
+        }
+        evals = flops = 0;
+    }
 
     std::string acc(uint32_t d) const { return "a" + std::to_string(d); }
     std::string accp(uint32_t d) const { return track ? "q" + std::to_string(d) : "no_prim"; }
@@ -111,17 +121,22 @@ struct Emitter {
                 std::snprintf(buf, sizeof buf, "    single_sd<%s, %s, %s, NP>(p, %s, %s);\n", code_name(code), tf(neg).c_str(),
                               tf(mx).c_str(), acc(depth).c_str(), centre_and_half(r).c_str());
             }
-            counted++;
+            evals += 1;
+            flops += flops_of_code(code);
         } else if (code == REC_RUN) {
             std::snprintf(buf, sizeof buf,
                           "    fold_run<%s, %s, %s, NP, %s>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, %uu, %uu, p, %s, %s);\n",
                           kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), tf(track).c_str(), r.a[0], r.a[1], acc(depth).c_str(),
                           accp(depth).c_str());
-            counted += r.a[1];
-        } else {   // REC_LATTICE
+            evals += r.a[1];
+            flops += r.a[1] * flops_of_kind(r.a[2]);
+        } else if (track) {   // REC_LATTICE
             std::snprintf(buf, sizeof buf,
-                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<%s, %s>(lds.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], n_evals[n]);\n",
-                          tf(track).c_str(), track ? "false" : "COUNT", r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
+                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<true, false>(lds.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], evals_unused[n]);\n",
+                          r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
+        } else {
+            std::snprintf(buf, sizeof buf, "    lattice_sd<COUNT, NP>(lds.lattice + %uu, %uu, %uu, p, %s, work);\n", r.a[1], r.a[0], r.prim,
+                          acc(depth).c_str());
         }
         s += buf;
     }
@@ -141,13 +156,19 @@ struct Emitter {
         }
     }
 
-    void children(const std::vector<Item> &items, uint32_t depth) {
+    // `free_of_charge`: the child whose evaluation the caller has booked already
+    void children(const std::vector<Item> &items, uint32_t depth, const Item *free_of_charge = nullptr) {
         std::vector<const Item *> order;
         for (const Item &it : items) order.push_back(&it);
         if (!track) std::stable_sort(order.begin(), order.end(), [&](const Item *x, const Item *y) { return rank(prog.recs, *x) < rank(prog.recs, *y); });
         for (const Item *it : order) {
             if (!it->is_list) {
+                const unsigned e = evals, f = flops;
                 leaf(prog.recs[it->rec], depth);
+                if (it == free_of_charge) {
+                    evals = e;
+                    flops = f;
+                }
             } else if (it->children.size() == 1 && !it->children[0].is_list && (prog.recs[it->children[0].rec].flags & 15u) <= REC_CROSS) {
                 // a list of one primitive is that primitive, negated if the list negates its first child,
                 // folded the way the list is folded into its parent
@@ -159,6 +180,7 @@ struct Emitter {
                 list(*it, depth);
             }
         }
+        book();
     }
 
     // A nested list.  In the distance-only walk the list is skipped when one of its children
@@ -201,10 +223,16 @@ struct Emitter {
                               tf(neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), code_name(code), centre_and_half(b).c_str());
             }
             s += buf;
+            // the test costs one evaluation of the bounding child; inside the list the compiler reuses it
+            evals += 1;
+            flops += flops_of_code(code);
+            book();
             s += "    if (__builtin_amdgcn_ballot_w64(need) != 0) {\n    keep_in_branch();\n";
+        } else {
+            book();
         }
         declare(d, identity);
-        children(it.children, d);
+        children(it.children, d, bound);
         if (track) {
             std::snprintf(buf, sizeof buf, "    fold_value<NP, true>(%uu, %s, %s, %s, %s);\n", pop.flags & (FOLD_NEG | FOLD_MAX), acc(d).c_str(),
                           accp(d).c_str(), acc(depth).c_str(), accp(depth).c_str());
@@ -220,40 +248,35 @@ struct Emitter {
 
 // body of sd() (track = false) or surface() (track = true)
 std::string emit_body(const HostProgram &prog, bool track) {
-    Emitter e{ prog, track };
+    Emitter e{ prog, track, std::string(), 0, 0, { 0 } };
     std::vector<Item> top;
     parse_children(prog.recs, 0, top);
     e.declare(0, prog.root_identity);
     if (!track) e.s += "    uint32_t no_prim[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;\n";
+    else e.s += "    uint32_t evals_unused[NP] = {};\n";
     e.children(top, 0);
-    char buf[256];
-    if (!track) {
-        std::snprintf(buf, sizeof buf, "    if (COUNT) { _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) n_evals[n] += %lluu; }\n", e.counted);
-        e.s += buf;
-    }
     e.s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : "") + " }\n";
     return e.s;
 }
 
 }  // namespace
 
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves) {
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting) {
     std::string s;
     s += "#include \"trace_kernel.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
-         "                                          float (&out_sd)[NP], uint32_t (&n_evals)[NP]) {\n";
+         "                                          float (&out_sd)[NP], Work (&work)[NP]) {\n";
     s += emit_body(prog, false);
     s += "}\n\n";
     s += "template <int NP>\nstatic __device__ __forceinline__ void surface(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
          "                                               float (&out_sd)[NP], uint32_t (&out_prim)[NP]) {\n";
-    s += "    uint32_t n_evals[NP] = {};\n";
     s += emit_body(prog, true);
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
     char buf[512];
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(256, %d) void rm_trace(const SceneView sc, const FrameView fr, Float4 *samples,\n"
-                  "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, false>(sc, fr, samples, counters);\n}\n\n",
-                  min_waves, points_per_lane);
+                  "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s>(sc, fr, samples, counters);\n}\n\n",
+                  min_waves, points_per_lane, counting ? "true" : "false");
     s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
          "        uint32_t *prim) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim);\n}\n";

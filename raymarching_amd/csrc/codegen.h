@@ -10,7 +10,7 @@
 namespace rmdev {
 
 // Kernels emitted: rm_trace (points_per_lane samples per lane, register budget for min_waves waves
-// per SIMD, no work counting) and rm_eval_sdf; signatures as the kernels of kernels.hip.
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves);
+// per SIMD, with or without work counting) and rm_eval_sdf; signatures as the kernels of kernels.hip.
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting);
 
 }  // namespace rmdev

@@ -301,6 +301,22 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
     acc = run;
 }
 
+// lattice_fold at NP points with the work booked (distance-only walk)
+template <bool COUNT, int NP>
+__device__ __forceinline__ void lattice_sd(const uint32_t *w, uint32_t levels, uint32_t first_row, const V3 (&p)[NP],
+                                           float (&acc)[NP], Work (&work)[NP]) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        uint32_t evals = 0, no_prim = kNoPrim;
+        lattice_fold<false, COUNT>(w, levels, first_row, p[n], acc[n], no_prim, evals);
+        if (COUNT) {
+            work[n].evals += evals;
+            work[n].flops += kFlopsCross * evals;
+        }
+    }
+}
+
+
 // distance of one SPHERE / BOX / CROSS record's primitive: centre c, half sizes (or radius) h
 template <uint32_t CODE>
 __device__ __forceinline__ float single_distance(V3 p, float cx, float cy, float cz, float h0, float h1, float h2) {
@@ -364,7 +380,7 @@ __device__ __forceinline__ V3 camera_view(ConstFloats m, V3 v, float w) {
 __device__ __forceinline__ float lerp1(float u, float v, float t) { return u + t * (v - u); }
 
 struct LaneCounts {
-    uint32_t sdf, steps, rays, evals, slots;
+    uint32_t sdf, steps, rays, evals, slots, flops;
 };
 
 }  // namespace rmdev

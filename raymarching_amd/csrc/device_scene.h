@@ -86,6 +86,21 @@ constexpr uint32_t kMaxDepth = 8;           // nested lists below the root
 constexpr uint32_t kNoPrim = 0xffffffffu;   // "colour of an empty list": black
 constexpr uint32_t kRunMin = 4;             // shorter homogeneous runs are emitted as single records
 
+// Work of one scene-SDF call at one point, filled by the counting kernel variants only:
+// primitive distance evaluations executed and their algorithmic FLOPs (11 per sphere, 9 per box,
+// 15 per cross, the fold's compare included; a sphere rejected by its square-root-free test counts
+// as evaluated; lattice axis scans count 3 evaluations per level visited).
+struct Work {
+    uint32_t evals, flops;
+};
+constexpr uint32_t kFlopsSphere = 11, kFlopsBox = 9, kFlopsCross = 15;
+constexpr uint32_t flops_of_code(uint32_t code) {
+    return code == REC_SPHERE ? kFlopsSphere : (code == REC_BOX ? kFlopsBox : kFlopsCross);
+}
+constexpr uint32_t flops_of_kind(uint32_t kind) {
+    return kind == K_SPHERE ? kFlopsSphere : ((kind == K_BOX || kind == K_BOX_ISO) ? kFlopsBox : kFlopsCross);
+}
+
 struct SceneView {
     const Rec *recs;
     const Float4 *pa;
@@ -116,6 +131,7 @@ struct WorkCounters {
     unsigned long long march_steps;
     unsigned long long rays;
     unsigned long long prim_evals;   // primitive distance evaluations (incl. lattice axis scans, 3 per level)
+    unsigned long long flops;        // algorithmic FLOPs of the primitive evaluations executed (see Work)
     unsigned long long march_slots;  // march-loop iterations x samples of the lanes that sat through them (live or idle)
 };
 

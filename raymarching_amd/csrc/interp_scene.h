@@ -22,7 +22,7 @@ namespace rmdev {
 struct InterpretedScene {
     template <int NP, bool COUNT>
     static __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
-                                             uint32_t (&n_evals)[NP]) {
+                                             Work (&work)[NP]) {
         float acc[NP];
         uint32_t no_prim[NP];
     #pragma unroll
@@ -62,15 +62,16 @@ struct InterpretedScene {
                 }
             } break;
             case REC_LATTICE | FOLD_NEG | FOLD_MAX: {
-    #pragma unroll
-                for (int n = 0; n < NP; ++n)
-                    lattice_fold<false, COUNT>(lds.lattice + cur[1], cur[0], cur[7], p[n], acc[n], no_prim[n], n_evals[n]);
+                lattice_sd<COUNT, NP>(lds.lattice + cur[1], cur[0], cur[7], p, acc, work);
             } break;
             default: {   // REC_RUN with any fold
                 const uint32_t first = cur[0], count = cur[1], kind = cur[2];
                 if (COUNT) {
     #pragma unroll
-                    for (int n = 0; n < NP; ++n) n_evals[n] += count;
+                    for (int n = 0; n < NP; ++n) {
+                        work[n].evals += count;
+                        work[n].flops += count * flops_of_kind(kind);
+                    }
                 }
                 switch (kind) {
                 case K_SPHERE: fold_run_kind<K_SPHERE, NP, false>(sc, cur[6], first, count, p, acc, no_prim); break;
@@ -83,7 +84,10 @@ struct InterpretedScene {
             }
             if (COUNT && (cur[6] & 15u) <= REC_CROSS) {
     #pragma unroll
-                for (int n = 0; n < NP; ++n) n_evals[n] += 1;
+                for (int n = 0; n < NP; ++n) {
+                    work[n].evals += 1;
+                    work[n].flops += flops_of_code(cur[6] & 15u);
+                }
             }
         }
     #pragma unroll

@@ -107,12 +107,11 @@ uint32_t lds_bytes_of(const SceneView &sc) { return (sc.lattice_words + sc.max_d
 }  // namespace
 
 hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
-                               hipStream_t stream) {
+                               WorkCounters *counters, hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0) return hipSuccess;
     const uint32_t pts = m.points_per_lane;
-    WorkCounters *counters = nullptr;
     SceneView sc_arg = sc;
     FrameView fr_arg = fr;
     void *args[] = { &sc_arg, &fr_arg, &samples, &counters };

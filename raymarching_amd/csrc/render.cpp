@@ -2,9 +2,9 @@
 //
 // Where the reference creates a hidden GLFW window, compiles shader.comp at run
 // time and allocates a texture plus three SSBOs (render.cpp:408-445), this
-// back-end only needs a HIP context: the kernels are compiled ahead of time for
-// gfx950 and buffers are sized on demand.  The three setup operators are kept
-// so that a caller written against the reference runs unchanged.
+// back-end needs a HIP context, and compiles kernels for the loaded scene where the
+// reference compiles its shader; buffers are sized on demand.  The three setup
+// operators are kept so that a caller written against the reference runs unchanged.
 #include "render.h"
 
 #include <iostream>
@@ -48,9 +48,14 @@ void setup::context(void) {
     report(rm_create(0, &g_ctx), "Failed to create HIP context");
 }
 
-// The kernels are part of the library image; there is nothing to compile or link.
+// Where the reference compiles and links shader.comp (render.cpp:428-437): generates and
+// compiles the kernels of the scene loaded so far (scene::load precedes the setup calls in the
+// reference's main.cpp:22-32), so that push() finds them in the library's code cache and costs
+// an upload only.  With no scene loaded yet there is nothing to compile; push() then does it.
 void setup::shaders(void) {
-    have_context("setup::shaders");
+    if (!have_context("setup::shaders")) return;
+    if (!scene::current().tree) return;
+    push();
 }
 
 // Device buffers are sized by push() and GPU(); nothing to pre-allocate.

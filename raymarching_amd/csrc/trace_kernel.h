@@ -1,6 +1,6 @@
 // trace_kernel.h -- the render kernel body, generic over the scene evaluator `Scene`
 // (InterpretedScene, or the straight-line evaluator generated for one scene):
-//     Scene::sd<NP, COUNT>(sc, lds, points, distances, evals)      distance only
+//     Scene::sd<NP, COUNT>(sc, lds, points, distances, work)       distance only
 //     Scene::surface<NP>(sc, lds, points, distances, primitives)   distance + colour-carrying primitive
 #pragma once
 
@@ -26,8 +26,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
         if (all_done) break;
         float sd[kPts];
-        uint32_t evals[kPts] = {};
-        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, evals);
+        Work work[kPts] = {};
+        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work);
         if (COUNT) cnt.slots += kPts;
 #pragma unroll
         for (int s = 0; s < kPts; ++s) {
@@ -38,7 +38,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
                 if (COUNT) {
                     cnt.sdf++;
                     cnt.steps++;
-                    cnt.evals += evals[s];
+                    cnt.evals += work[s].evals;
+                    cnt.flops += work[s].flops;
                 }
             }
         }
@@ -54,9 +55,9 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Float4 *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
-    __shared__ unsigned long long block_counts[5];
+    __shared__ unsigned long long block_counts[6];
     if (COUNT) {
-        if (threadIdx.x < 5) block_counts[threadIdx.x] = 0;
+        if (threadIdx.x < 6) block_counts[threadIdx.x] = 0;
     }
     const Lds lds = stage_lds(sc);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -65,7 +66,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t sh = fr.band_count * fr.band_rows * k;
     const uint32_t sx0 = blockIdx.x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
     const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    LaneCounts cnt = { 0, 0, 0, 0, 0 };
+    LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
     const float AR = (float)fr.width / (float)fr.height;
@@ -154,13 +155,14 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                         q[s] = side == 0 ? v3(hit[s].x + e.x, hit[s].y + e.y, hit[s].z + e.z)
                                          : v3(hit[s].x - e.x, hit[s].y - e.y, hit[s].z - e.z);
                     float sd[kPts];
-                    uint32_t evals[kPts] = {};
-                    Scene::template sd<kPts, COUNT>(sc, lds, q, sd, evals);
+                    Work work[kPts] = {};
+                    Scene::template sd<kPts, COUNT>(sc, lds, q, sd, work);
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) {
                         if (COUNT && live[s]) {
                             cnt.sdf++;
-                            cnt.evals += evals[s];
+                            cnt.evals += work[s].evals;
+                            cnt.flops += work[s].flops;
                         }
                         const float diff = plus[s] - sd[s];
                         plus[s] = side == 0 ? sd[s] : plus[s];
@@ -206,6 +208,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         atomicAdd(&block_counts[2], (unsigned long long)cnt.rays);
         atomicAdd(&block_counts[3], (unsigned long long)cnt.evals);
         atomicAdd(&block_counts[4], (unsigned long long)cnt.slots);
+        atomicAdd(&block_counts[5], (unsigned long long)cnt.flops);
         __syncthreads();
         if (threadIdx.x == 0) {
             atomicAdd(&counters->sdf_calls, block_counts[0]);
@@ -213,6 +216,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             atomicAdd(&counters->rays, block_counts[2]);
             atomicAdd(&counters->prim_evals, block_counts[3]);
             atomicAdd(&counters->march_slots, block_counts[4]);
+            atomicAdd(&counters->flops, block_counts[5]);
         }
     }
 }

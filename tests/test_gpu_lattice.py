@@ -113,8 +113,16 @@ def test_default_frame_both_evaluators_hash(rm, renderer):
         assert hashlib.sha256(img.tobytes()).hexdigest() == rec["sha256_f32"], f"lattice={lattice}"
         assert c["sdf_calls"] == rec["counters"]["sdf_calls"]
         evals[lattice] = c["prim_evals"]
-    assert evals[False] == rec["counters"]["prim_evals"]      # exhaustive: every primitive at every call
-    assert evals[True] < evals[False] // 5
+        assert c["compiled_kernel"] == (1 if renderer.kernel_mode == "compiled" else 0)
+        if not lattice and renderer.kernel_mode == "interpreted":
+            # the record walker visits every primitive at every call
+            assert c["prim_evals"] == rec["counters"]["prim_evals"]
+            assert c["flops_executed"] == c["sdf_calls"] * c["flops_per_sdf"]
+        else:
+            assert 0 < c["flops_executed"] < c["sdf_calls"] * c["flops_per_sdf"]
+    # the compiled kernels skip lists a bounding child rules out, even with every primitive listed
+    assert evals[False] <= rec["counters"]["prim_evals"]
+    assert evals[True] < rec["counters"]["prim_evals"] // 5
 
 
 def test_menger4_frame_bit_identical(rm, oracle, renderer):
