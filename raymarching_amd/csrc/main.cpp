@@ -1,0 +1,125 @@
+// main.cpp -- command-line driver on the render:: operators, in the shape of the reference's
+// main() (/root/reference/source/main.cpp:17-88): load the scene, set up, push, render, report the
+// same timing lines, write the image.  What the reference fixes at compile time
+// (constants.h:11-27) is a flag here.
+//
+//   raymarch [--scene scene/objects.txt] [--width 1024] [--height 768] [--ssaa 3] [--iterations 1000]
+//            [--frames 1] [--out out_gpu.png] [--raw out_gpu.rgba] [--exhaustive] [--interpreted]
+//
+// The CPU renders of the reference's main() (render::CPU / render::OMP) are not part of this
+// library; their lines are printed as "not built" so that the report keeps its shape.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "render.h"
+#include "scene.h"
+
+namespace {
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int usage(const char *argv0) {
+    std::cout << "usage: " << argv0
+              << " [--scene PATH] [--width W] [--height H] [--ssaa K] [--iterations N] [--frames N]\n"
+                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted]\n";
+    return 2;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::string scene_path = "scene/objects.txt", out_png = "out_gpu.png", out_raw;
+    int frames = 1;
+    bool exhaustive = false, interpreted = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
+        const char *v = nullptr;
+        if (a == "--exhaustive") exhaustive = true;
+        else if (a == "--interpreted") interpreted = true;
+        else if ((v = value()) == nullptr) return usage(argv[0]);
+        else if (a == "--scene") scene_path = v;
+        else if (a == "--width") constants::params.width = (uint32_t)std::atoi(v);
+        else if (a == "--height") constants::params.height = (uint32_t)std::atoi(v);
+        else if (a == "--ssaa") constants::params.kernel = (uint32_t)std::atoi(v);
+        else if (a == "--iterations") constants::params.iterations = std::atoi(v);
+        else if (a == "--frames") frames = std::atoi(v);
+        else if (a == "--out") out_png = v;
+        else if (a == "--raw") out_raw = v;
+        else return usage(argv[0]);
+    }
+    if (frames < 1) frames = 1;
+    const rm_params &p = constants::params;
+
+    std::cout << "...Loading scene" << std::endl;
+    scene::load(scene_path.c_str());
+
+    std::cout << "...Setting up context" << std::endl;
+    render::setup::context();
+    if (!render::ok()) return 1;
+    if (exhaustive) rm_set_evaluator(render::context(), RM_EVAL_EXHAUSTIVE);
+    if (interpreted) rm_set_kernel_mode(render::context(), RM_KERNEL_INTERPRETED);
+
+    std::cout << "...Compiling shaders" << std::endl;
+    auto t0 = std::chrono::steady_clock::now();
+    render::setup::shaders();
+    const double compile_s = seconds_since(t0);
+    if (!render::ok()) return 1;
+
+    std::cout << "...Generating buffers" << std::endl;
+    render::setup::buffers();
+
+    std::cout << "...Rendering" << std::endl;
+    std::cout << "Render with CPU (1 thread):\tnot built (the CPU path is the external baseline)" << std::endl;
+    std::cout << "Render with OpenMP:\t\tnot built (the CPU path is the external baseline)" << std::endl;
+
+    std::vector<unsigned char> image((size_t)p.width * p.height * 4);
+
+    t0 = std::chrono::steady_clock::now();
+    render::push();
+    const double push_s = seconds_since(t0);
+    if (!render::ok()) return 1;
+
+    render::GPU(image.data());   // first frame: device buffers are sized here
+    if (!render::ok()) return 1;
+    t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++) render::GPU(image.data());
+    const double render_s = seconds_since(t0) / frames;
+    if (!render::ok()) return 1;
+
+    rm_counters c{};
+    rm_get_counters(render::context(), &c);
+    const double rays = (double)p.width * p.height * p.kernel * p.kernel * (1.0 + (double)scene::current().lights.size());
+
+    std::cout << "Render with GPU:\t\t" << render_s << "s" << std::endl;
+    std::cout << "Copy to GPU:\t\t\t" << push_s << "s" << std::endl;
+    std::cout << "Render + Copy on GPU:\t\t" << render_s + push_s << "s" << std::endl;
+    std::cout << "Kernel compile:\t\t\t" << compile_s << "s" << std::endl;
+    std::cout << "Trace kernel:\t\t\t" << c.kernel_ms * 1e-3 << "s (" << (c.compiled_kernel ? "compiled for the scene" : "record walker")
+              << "), resolve " << c.resolve_ms * 1e-3 << "s" << std::endl;
+    std::cout << "Throughput:\t\t\t" << rays / render_s / 1e6 << " Mrays/s (" << (uint64_t)rays << " rays per frame, " << frames
+              << " frame" << (frames > 1 ? "s" : "") << " timed, host image included)" << std::endl;
+
+    if (!out_png.empty()) {
+        if (rm_write_png(out_png.c_str(), image.data(), p.width, p.height) != RM_OK)
+            std::cout << "[Error] " << rm_last_error() << std::endl;
+    }
+    if (!out_raw.empty()) {
+        if (FILE *f = std::fopen(out_raw.c_str(), "wb")) {
+            std::fwrite(image.data(), 1, image.size(), f);
+            std::fclose(f);
+        } else {
+            std::cout << "[Error] cannot write " << out_raw << std::endl;
+        }
+    }
+
+    render::destroy();
+    return 0;
+}

@@ -1,0 +1,40 @@
+"""The command-line driver (raymarching_amd/csrc/main.cpp) against the oracle: same report lines as the
+reference's main() (/root/reference/source/main.cpp:43-77) and a frame identical to the CPU restatement's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+pytestmark = pytest.mark.gpu
+
+DRIVER = os.path.join(ROOT, "raymarching_amd", "raymarch")
+
+
+def test_driver_report_and_frame(oracle, tmp_path):
+    assert os.path.isfile(DRIVER), "build the driver first (make -C raymarching_amd/csrc)"
+    raw, png = tmp_path / "out.rgba", tmp_path / "out.png"
+    cmd = [DRIVER, "--scene", scene_path("menger2.txt"), "--width", "128", "--height", "96", "--ssaa", "2",
+           "--frames", "2", "--raw", str(raw), "--out", str(png)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for line in ("...Loading scene", "...Setting up context", "...Compiling shaders", "...Generating buffers", "...Rendering",
+                 "Render with GPU:", "Copy to GPU:", "Render + Copy on GPU:", "Mrays/s"):
+        assert line in out.stdout, out.stdout
+    assert "[Error]" not in out.stdout
+    img = np.fromfile(raw, dtype=np.uint8).reshape(96, 128, 4)
+    ref, _ = oracle.Scene(scene_path("menger2.txt")).render(oracle.default_params(width=128, height=96, kernel=2))
+    assert np.array_equal(img, oracle.quantize(ref))
+    assert png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+
+
+def test_driver_reports_a_missing_scene_like_the_reference(tmp_path):
+    """scene::load leaves the scene empty when the file is missing (scene.cpp:95-98); the frame is then black."""
+    raw = tmp_path / "out.rgba"
+    out = subprocess.run([DRIVER, "--scene", str(tmp_path / "absent.txt"), "--width", "32", "--height", "16", "--ssaa", "1",
+                          "--raw", str(raw), "--out", ""], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    img = np.fromfile(raw, dtype=np.uint8).reshape(16, 32, 4)
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 255).all()
