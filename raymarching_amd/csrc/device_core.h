@@ -235,6 +235,26 @@ __device__ __forceinline__ void axis_range(const uint32_t *tab, int n, float p, 
     }
 }
 
+// One row of crosses: two axis terms fixed (d1, d2 in axis order), the third axis running over all
+// n centres of the level.  AXIS = the running axis; the operands keep their x, y, z places in the
+// reference's sum.  `fixed_ones` = digit masks of the two fixed indices, or-ed.
+template <int AXIS>
+__device__ __forceinline__ float lattice_row(const uint32_t *T, const uint32_t *ONES, int n, float pt, float h, float d1,
+                                             float d2, uint32_t fixed_ones, float run) {
+    for (int k = 0; k < n; ++k) {
+        const float t = axis_term(T, k, pt, h);
+        const float v = -(AXIS == 0 ? cross_value(t, d1, d2) : (AXIS == 1 ? cross_value(d1, t, d2) : cross_value(d1, d2, t)));
+        run = (ONES[k] & fixed_ones) ? run : __builtin_fmaxf(run, v);
+    }
+    return run;
+}
+
+// index of the centre nearest to p (exact enough: see the caller's 0.45-spacing condition)
+__device__ __forceinline__ int nearest_index(float p, float origin, float inv_spacing, int last) {
+    const float u = (p - origin) * inv_spacing + 0.5f;
+    return (int)__builtin_fminf(__builtin_fmaxf(u, 0.0f), (float)last);
+}
+
 template <bool TRACK, bool COUNT>
 __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels, uint32_t first_row, V3 p, float &acc,
                                              uint32_t &acc_prim, uint32_t &n_evals) {
@@ -251,22 +271,45 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
         const uint32_t *Y = X + n;
         const uint32_t *Z = Y + n;
         const uint32_t *ONES = Z + n;
+        if (COUNT) n_evals += 3;
+        if ((h + tau) * inv <= 0.45f) {
+            // The usual case (p is not deep inside solid material): an axis term below tau needs
+            // |p - centre| < h + tau <= 0.45 spacings, so on each axis only the centre nearest to p can
+            // be in range.  (Tables are evenly spaced to 1 % of a step, and the three axes' spacings
+            // agree to 1 %: whenever some centre is in range, it is the one the estimate picks; when
+            // none is, the pick fails the test.)  One round of independent loads, no scans.
+            const int ix = nearest_index(p.x, __uint_as_float(w[kLatOrigin + 3 * l]), inv, n - 1);
+            const int iy = nearest_index(p.y, __uint_as_float(w[kLatOrigin + 3 * l + 1]), inv, n - 1);
+            const int iz = nearest_index(p.z, __uint_as_float(w[kLatOrigin + 3 * l + 2]), inv, n - 1);
+            const float dx = axis_term(X, ix, p.x, h), dy = axis_term(Y, iy, p.y, h), dz = axis_term(Z, iz, p.z, h);
+            const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
+            const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
+            // two zero offsets at one subdivision step: no such sub-cube
+            if (bx && by && !(ox & oy)) {
+                run = lattice_row<2>(Z, ONES, n, p.z, h, dx, dy, ox | oy, run);
+                if (COUNT) n_evals += n;
+            }
+            if (bx && bz && !(ox & oz)) {
+                run = lattice_row<1>(Y, ONES, n, p.y, h, dx, dz, ox | oz, run);
+                if (COUNT) n_evals += n;
+            }
+            if (by && bz && !(oy & oz)) {
+                run = lattice_row<0>(X, ONES, n, p.x, h, dy, dz, oy | oz, run);
+                if (COUNT) n_evals += n;
+            }
+            continue;
+        }
         int lox, hix, loy, hiy, loz, hiz;
         axis_range(X, n, p.x, h, inv, tau, lox, hix);
         axis_range(Y, n, p.y, h, inv, tau, loy, hiy);
         axis_range(Z, n, p.z, h, inv, tau, loz, hiz);
-        if (COUNT) n_evals += 3;
         const bool bx = lox <= hix, by = loy <= hiy, bz = loz <= hiz;
         if (bx && by) {
             for (int i = lox; i <= hix; ++i)
                 for (int j = loy; j <= hiy; ++j) {
                     const uint32_t oi = ONES[i], oj = ONES[j];
-                    if (oi & oj) continue;   // two zero offsets at one subdivision step: no such sub-cube
-                    const float dx = axis_term(X, i, p.x, h), dy = axis_term(Y, j, p.y, h);
-                    for (int k = 0; k < n; ++k) {
-                        const float v = -cross_value(dx, dy, axis_term(Z, k, p.z, h));
-                        run = (ONES[k] & (oi | oj)) ? run : __builtin_fmaxf(run, v);
-                    }
+                    if (oi & oj) continue;
+                    run = lattice_row<2>(Z, ONES, n, p.z, h, axis_term(X, i, p.x, h), axis_term(Y, j, p.y, h), oi | oj, run);
                     if (COUNT) n_evals += n;
                 }
         }
@@ -275,11 +318,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oi = ONES[i], ok = ONES[k];
                     if (oi & ok) continue;
-                    const float dx = axis_term(X, i, p.x, h), dz = axis_term(Z, k, p.z, h);
-                    for (int j = 0; j < n; ++j) {
-                        const float v = -cross_value(dx, axis_term(Y, j, p.y, h), dz);
-                        run = (ONES[j] & (oi | ok)) ? run : __builtin_fmaxf(run, v);
-                    }
+                    run = lattice_row<1>(Y, ONES, n, p.y, h, axis_term(X, i, p.x, h), axis_term(Z, k, p.z, h), oi | ok, run);
                     if (COUNT) n_evals += n;
                 }
         }
@@ -288,11 +327,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oj = ONES[j], ok = ONES[k];
                     if (oj & ok) continue;
-                    const float dy = axis_term(Y, j, p.y, h), dz = axis_term(Z, k, p.z, h);
-                    for (int i = 0; i < n; ++i) {
-                        const float v = -cross_value(axis_term(X, i, p.x, h), dy, dz);
-                        run = (ONES[i] & (oj | ok)) ? run : __builtin_fmaxf(run, v);
-                    }
+                    run = lattice_row<0>(X, ONES, n, p.x, h, axis_term(Y, j, p.y, h), axis_term(Z, k, p.z, h), oj | ok, run);
                     if (COUNT) n_evals += n;
                 }
         }

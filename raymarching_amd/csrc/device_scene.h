@@ -77,9 +77,10 @@ struct Float4 { float x, y, z, w; };
 // A block of 32-bit words per lattice:
 //   [0] levels  [2] magnitude bound (float)  [4..11] half[l]  [12..19] 1/spacing[l]
 //   [20..27] word offset of level l's tables: X[3^l], Y[3^l], Z[3^l], ONES[3^l]
+//   [28..51] X_l[0], Y_l[0], Z_l[0] per level (saves a dependent table read in the index estimate)
 //   ONES[i] = bit mask of the digit positions where index i has digit 1.
 constexpr uint32_t kLatticeMaxLevels = 8;
-constexpr uint32_t kLatHalf = 4, kLatInvSpacing = 12, kLatOffset = 20, kLatHeaderWords = 28;
+constexpr uint32_t kLatHalf = 4, kLatInvSpacing = 12, kLatOffset = 20, kLatOrigin = 28, kLatHeaderWords = 52;
 constexpr uint32_t kLatticeMaxWords = 12288;   // 48 KiB of LDS per workgroup at most
 
 constexpr uint32_t kMaxDepth = 8;           // nested lists below the root

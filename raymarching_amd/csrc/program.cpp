@@ -89,18 +89,13 @@ struct LatticeMatcher {
         return true;
     }
 
-    static bool evenly_spaced(const std::vector<float> &t, float &spacing) {
-        if (t.size() < 2) {
-            spacing = 0.0f;
-            return true;
-        }
-        const double step = ((double)t.back() - (double)t.front()) / (double)(t.size() - 1);
+    // sorted, and every entry within 1 % of a step of front + i * step
+    static bool on_grid(const std::vector<float> &t, double step) {
         if (!(step > 0.0) || !std::isfinite(step)) return false;
         for (size_t i = 0; i < t.size(); i++) {
             if (i && !(t[i - 1] < t[i])) return false;
             if (std::fabs((double)t[i] - ((double)t.front() + step * (double)i)) > 0.01 * step) return false;
         }
-        spacing = (float)step;
         return true;
     }
 
@@ -118,12 +113,12 @@ struct LatticeMatcher {
         for (uint32_t l = 0; l < n; l++) {
             if (!(half[l] > 0.0f) || !std::isfinite(half[l])) return false;
             if (l && !(half[l] < half[l - 1])) return false;
-            float sx, sy, sz;
-            if (!evenly_spaced(X[l], sx) || !evenly_spaced(Y[l], sy) || !evenly_spaced(Z[l], sz)) return false;
             if (l) {
-                // one spacing per level is used for the index estimate; bars of one level must not overlap
-                const float s = sx;
-                if (std::fabs(sy - s) > 0.01f * s || std::fabs(sz - s) > 0.01f * s) return false;
+                // The kernels estimate indices on all three axes with ONE spacing per level (the x table's,
+                // as emit() stores it): every table must lie on that grid, and bars of one level must not
+                // overlap.
+                const float s = (X[l].back() - X[l].front()) / (float)(X[l].size() - 1);
+                if (!on_grid(X[l], (double)s) || !on_grid(Y[l], (double)s) || !on_grid(Z[l], (double)s)) return false;
                 if (!(2.0f * half[l] < s)) return false;
             }
         }
@@ -144,6 +139,9 @@ struct LatticeMatcher {
             put_f(base + kLatInvSpacing + l, spacing > 0.0f ? 1.0f / spacing : 0.0f);
             const uint32_t m = pow3(l);
             out[base + kLatOffset + l] = (uint32_t)out.size() - base;
+            put_f(base + kLatOrigin + 3 * l, X[l].front());
+            put_f(base + kLatOrigin + 3 * l + 1, Y[l].front());
+            put_f(base + kLatOrigin + 3 * l + 2, Z[l].front());
             for (float v : X[l]) out.push_back(bits_of(v));
             for (float v : Y[l]) out.push_back(bits_of(v));
             for (float v : Z[l]) out.push_back(bits_of(v));
