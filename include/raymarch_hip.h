@@ -94,7 +94,7 @@ typedef struct rm_counters {
     double   compile_ms;   /* time rm_set_scene spent compiling the scene's kernels
                               (0: interpreted mode, or code object found in the cache) */
     uint32_t compiled_kernel; /* 1 if the last render ran the scene's own kernel      */
-    uint32_t reserved;
+    uint32_t tiles_by_cost; /* 1 if the last render launched its tiles in cost order             */
     uint64_t march_slots;  /* march-loop iterations x samples of the lanes that sat through them,
                               live or idle: march_steps / march_slots = lane utilisation of
                               the sphere-tracing loop                                   */
@@ -170,6 +170,19 @@ int rm_set_evaluator(rm_context *ctx, int evaluator);
  */
 typedef enum rm_kernel_mode { RM_KERNEL_INTERPRETED = 0, RM_KERNEL_COMPILED = 1 } rm_kernel_mode;
 int rm_set_kernel_mode(rm_context *ctx, int mode);
+
+/*
+ * Order in which the trace kernel's 16x16-sample tiles are started (no counterpart in the
+ * reference; the frame is the same either way).
+ *   RM_TILES_BY_COST  (default) the first render of a configuration -- scene upload, parameters,
+ *                     row bands -- times every tile; later renders of the same configuration
+ *                     start the expensive tiles first, which hides the long-running tiles of
+ *                     dense regions behind the cheap ones (the cost of one host-side sort after
+ *                     that first render);
+ *   RM_TILES_NATURAL  row-major order, nothing measured.
+ */
+typedef enum rm_tile_scheduling { RM_TILES_NATURAL = 0, RM_TILES_BY_COST = 1 } rm_tile_scheduling;
+int rm_set_tile_scheduling(rm_context *ctx, int mode);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -39,7 +39,7 @@ class Counters(C.Structure):
     _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
                 ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("lattice_prims", C.c_uint64),
                 ("flops_per_sdf", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("compile_ms", C.c_double), ("compiled_kernel", C.c_uint32), ("reserved", C.c_uint32), ("march_slots", C.c_uint64), ("flops_executed", C.c_uint64)]
+                ("compile_ms", C.c_double), ("compiled_kernel", C.c_uint32), ("tiles_by_cost", C.c_uint32), ("march_slots", C.c_uint64), ("flops_executed", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -80,6 +80,7 @@ def lib():
     L.rm_set_counting.argtypes = [vp, C.c_int]
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
+    L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rm_stream.argtypes = [vp]
     L.rm_stream.restype = vp
@@ -215,6 +216,10 @@ class Renderer:
         """True (default): kernels generated and compiled per scene; False: the record-walking kernel.
         Takes effect at the next set_scene."""
         _check(lib().rm_set_kernel_mode(self._h, 1 if compiled else 0), "rm_set_kernel_mode")
+
+    def set_tile_scheduling(self, by_cost):
+        """True (default): after the first frame of a configuration, expensive tiles are started first."""
+        _check(lib().rm_set_tile_scheduling(self._h, 1 if by_cost else 0), "rm_set_tile_scheduling")
 
     def set_evaluator(self, lattice):
         """True: recognise Menger lattices (default); False: visit every primitive.  Applies to the next set_scene."""

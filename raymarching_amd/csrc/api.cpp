@@ -7,7 +7,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <numeric>
 #include <cstring>
 #include <new>
 #include <string>
@@ -83,6 +85,20 @@ struct rm_context {
     DeviceArray<float> d_points, d_sd, d_camera;
     DeviceArray<uint32_t> d_prim, d_lattice, d_row_prim;
 
+    // Cost-ordered tile launch: the first frame of a configuration (scene, parameters, row bands,
+    // kernel shape) measures every tile's duration, later frames start the expensive tiles first.
+    struct OrderKey {
+        rm_params params;
+        rm_rows rows;
+        uint64_t scene_serial;
+        uint32_t points_per_lane;
+    };
+    int tile_scheduling = RM_TILES_BY_COST;
+    uint64_t scene_serial = 0;
+    OrderKey order_key{};
+    bool order_ready = false;
+    DeviceArray<uint32_t> d_tile_order, d_tile_cost;
+
     rm_counters last{};
 };
 
@@ -115,8 +131,34 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
     if (rows.band_rows == 0 || rows.band_count == 0 || rows.band_stride == 0)
         return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
     RM_HIP(hipSetDevice(ctx->device));
-    const rmdev::FrameView fr = frame_view(ctx->params, rows);
+    rmdev::FrameView fr = frame_view(ctx->params, rows);
     RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
+    const bool compiled = ctx->module.loaded();
+    const bool wide_runs = ctx->program.run_prims >= 64;
+
+    // ---- tile schedule of this launch
+    const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
+    const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
+    const size_t n_tiles = (size_t)((sw + 16u * pts - 1u) / (16u * pts)) * ((sh + 15u) / 16u);
+    const bool scheduled = ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && n_tiles > 1;
+    bool measuring = false;
+    if (scheduled) {
+        rm_context::OrderKey key{};
+        key.params = ctx->params;
+        key.rows = rows;
+        key.scene_serial = ctx->scene_serial;
+        key.points_per_lane = pts;
+        if (!ctx->order_ready || std::memcmp(&key, &ctx->order_key, sizeof key) != 0) {
+            ctx->order_key = key;
+            ctx->order_ready = false;
+            measuring = true;
+            RM_HIP(ctx->d_tile_cost.reserve(n_tiles));
+            RM_HIP(ctx->d_tile_order.reserve(n_tiles));
+            fr.tile_cost = ctx->d_tile_cost.ptr;
+        } else {
+            fr.tile_order = ctx->d_tile_order.ptr;
+        }
+    }
     rmdev::WorkCounters *d_cnt = nullptr;
     if (ctx->counting) {
         RM_HIP(ctx->d_counters.reserve(1));
@@ -124,7 +166,6 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    const bool compiled = ctx->module.loaded();
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
         if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
@@ -132,7 +173,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
     if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
-    else RM_HIP(rmdev::launch_trace(ctx->scene, fr, ctx->program.run_prims >= 64, ctx->d_samples.ptr, d_cnt, ctx->stream));
+    else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -140,7 +181,16 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
     float ms_trace = 0.0f, ms_resolve = 0.0f;
     RM_HIP(hipEventElapsedTime(&ms_trace, ctx->ev[0], ctx->ev[1]));
     RM_HIP(hipEventElapsedTime(&ms_resolve, ctx->ev[1], ctx->ev[2]));
+    if (measuring) {
+        std::vector<uint32_t> cost(n_tiles), order(n_tiles);
+        RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, order.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ctx->order_ready = true;
+    }
     ctx->last = rm_counters{};
+    ctx->last.tiles_by_cost = (scheduled && !measuring) ? 1u : 0u;
     ctx->last.kernel_ms = ms_trace;
     ctx->last.resolve_ms = ms_resolve;
     ctx->last.prims = ctx->program.n_prims;
@@ -202,6 +252,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
     ctx->module.unload();
     ctx->counting_module.unload();
+    ctx->d_tile_order.release(); ctx->d_tile_cost.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -260,6 +311,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.lattice = ctx->d_lattice.ptr;
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;
+    ctx->scene_serial++;
     ctx->module.unload();
     ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
@@ -333,6 +385,14 @@ int rm_set_kernel_mode(rm_context *ctx, int mode) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (mode != RM_KERNEL_INTERPRETED && mode != RM_KERNEL_COMPILED) return fail(RM_ERR_INVALID, "rm_set_kernel_mode: unknown mode");
     ctx->kernel_mode = mode;
+    return RM_OK;
+}
+
+int rm_set_tile_scheduling(rm_context *ctx, int mode) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
+    ctx->tile_scheduling = mode;
+    ctx->order_ready = false;
     return RM_OK;
 }
 

@@ -125,6 +125,12 @@ struct FrameView {
     float saturation, surface_eps, offset_eps;
     // row bands rendered by this launch (see rm_rows)
     uint32_t band_rows, first_band, band_stride, band_count;
+    // Tile scheduling of the trace kernel (either may be null).  Workgroup b renders tile
+    // tile_order[b] (tiles numbered row-major over the launch's sample image) instead of tile b, and
+    // every workgroup stores how long it ran, in 10 ns ticks, into tile_cost[its tile].  The host
+    // sorts one frame's costs to start the next frame's expensive tiles first.
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
 };
 
 struct WorkCounters {

@@ -64,8 +64,12 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
-    const uint32_t sx0 = blockIdx.x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
-    const uint32_t sy = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const unsigned long long started = fr.tile_cost ? wall_clock64() : 0ull;
+    const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t tile = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
+    const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
+    const uint32_t sx0 = tile_x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
+    const uint32_t sy = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
     LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
@@ -200,6 +204,12 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             color = v3(light * base.x, light * base.y, light * base.z);
         }
         samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
+    }
+
+    if (fr.tile_cost) {
+        // the workgroup's duration as its last wave sees it (waves of a workgroup start together)
+        __syncthreads();
+        if (threadIdx.x == 0) fr.tile_cost[tile] = (uint32_t)(wall_clock64() - started);
     }
 
     if (COUNT) {

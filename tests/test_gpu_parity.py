@@ -257,3 +257,22 @@ def test_ties_between_kinds_keep_the_earlier_child(rm, oracle, renderer, mode, c
     assert sd.tobytes() == osd.tobytes()
     colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)
     np.testing.assert_array_equal(colours[prim], orgb)
+
+
+def test_cost_ordered_tiles_render_the_same_frame(rm, renderer):
+    """The second and later renders of a configuration start expensive tiles first: same bytes, flag set."""
+    renderer.set_params(rm.default_params(width=320, height=200, kernel=2))
+    renderer.set_scene(rm.Scene(scene_path("default.txt")))
+    first = renderer.render_f32()
+    assert renderer.counters()["tiles_by_cost"] == 0          # the measuring frame runs in natural order
+    for _ in range(2):
+        again = renderer.render_f32()
+        assert renderer.counters()["tiles_by_cost"] == 1
+        assert again.tobytes() == first.tobytes()
+    renderer.set_tile_scheduling(False)
+    try:
+        natural = renderer.render_f32()
+        assert renderer.counters()["tiles_by_cost"] == 0
+        assert natural.tobytes() == first.tobytes()
+    finally:
+        renderer.set_tile_scheduling(True)
