@@ -137,6 +137,22 @@ int rm_render_f32(rm_context *ctx, float *host_image);
  * call returns after the stream has been synchronised. */
 int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8);
 
+/*
+ * The same without waiting (the reference's render::GPU blocks in glGetTexImage, render.cpp:474;
+ * these exist so that a caller can keep several frames in flight, e.g. two contexts on two
+ * streams, or overlap the render with a collective that gathers the previous frame).
+ *   rm_enqueue_device  queues trace + resolve on the context's stream and returns.  A context
+ *                      renders one frame at a time through one scratch buffer: frames queued on
+ *                      it run in order.  Tile costs are not measured by queued frames; they use
+ *                      the order a synchronous render of the same configuration left behind.
+ *   rm_wait            waits for the stream and books the last queued frame (rm_get_counters).
+ *   rm_set_stream      makes the context work on the caller's hipStream_t (NULL: back to its own),
+ *                      so that its kernels are ordered with the caller's other work on it.
+ */
+int rm_enqueue_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8);
+int rm_wait(rm_context *ctx);
+int rm_set_stream(rm_context *ctx, void *hip_stream);
+
 /* Scene SDF at n host points (xyz interleaved): signed distance and the index
  * (depth-first primitive order) of the primitive whose colour wins.  Exposes
  * the device evaluator of Body::List::SDF (body.cpp:66-111) for parity tests. */

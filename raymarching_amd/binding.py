@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -76,6 +76,9 @@ def lib():
     L.rm_render_rgba8.argtypes = [vp, vp]
     L.rm_render_f32.argtypes = [vp, vp]
     L.rm_render_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_enqueue_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_wait.argtypes = [vp]
+    L.rm_set_stream.argtypes = [vp, vp]
     L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.rm_set_counting.argtypes = [vp, C.c_int]
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
@@ -204,6 +207,17 @@ class Renderer:
     def render_device(self, rows, f32_ptr=None, rgba8_ptr=None):
         """rows: Rows; pointers are raw device addresses (e.g. torch.Tensor.data_ptr())."""
         _check(lib().rm_render_device(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_render_device")
+
+    def enqueue_device(self, rows, f32_ptr=None, rgba8_ptr=None):
+        """render_device without waiting; pair with wait()."""
+        _check(lib().rm_enqueue_device(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_enqueue_device")
+
+    def wait(self):
+        _check(lib().rm_wait(self._h), "rm_wait")
+
+    def set_stream(self, hip_stream):
+        """hip_stream: raw hipStream_t (e.g. torch.cuda.Stream().cuda_stream) or None for the context's own."""
+        _check(lib().rm_set_stream(self._h, hip_stream), "rm_set_stream")
 
     def eval_sdf(self, xyz):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)

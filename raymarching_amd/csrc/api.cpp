@@ -99,6 +99,14 @@ struct rm_context {
     bool order_ready = false;
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
 
+    // the frame enqueued last and not yet booked by finish_bands
+    struct Pending {
+        bool active = false, measuring = false, by_cost = false, compiled = false, counted = false;
+        size_t n_tiles = 0;
+    };
+    Pending pending;
+    hipStream_t own_stream = nullptr;   // created by rm_create; `stream` may be the caller's instead
+
     rm_counters last{};
 };
 
@@ -127,7 +135,9 @@ rmdev::FrameView frame_view(const rm_params &p, const rm_rows &rows) {
 }
 
 // Trace + resolve of the given bands into device buffers; synchronises the stream.
-int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8) {
+// Puts trace + resolve of the given bands on the context's stream.  may_measure: this frame may run in
+// natural tile order with every tile timed (its caller will call finish_bands before the next frame).
+int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure) {
     if (rows.band_rows == 0 || rows.band_count == 0 || rows.band_stride == 0)
         return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
     RM_HIP(hipSetDevice(ctx->device));
@@ -135,28 +145,30 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
     RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
     const bool compiled = ctx->module.loaded();
     const bool wide_runs = ctx->program.run_prims >= 64;
+    rm_context::Pending &pend = ctx->pending;
+    pend = rm_context::Pending{};
+    pend.compiled = compiled;
 
     // ---- tile schedule of this launch
     const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
-    const size_t n_tiles = (size_t)((sw + 16u * pts - 1u) / (16u * pts)) * ((sh + 15u) / 16u);
-    const bool scheduled = ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && n_tiles > 1;
-    bool measuring = false;
-    if (scheduled) {
+    pend.n_tiles = (size_t)((sw + 16u * pts - 1u) / (16u * pts)) * ((sh + 15u) / 16u);
+    if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
         rm_context::OrderKey key{};
         key.params = ctx->params;
         key.rows = rows;
         key.scene_serial = ctx->scene_serial;
         key.points_per_lane = pts;
-        if (!ctx->order_ready || std::memcmp(&key, &ctx->order_key, sizeof key) != 0) {
+        if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
+            fr.tile_order = ctx->d_tile_order.ptr;
+            pend.by_cost = true;
+        } else if (may_measure) {
             ctx->order_key = key;
             ctx->order_ready = false;
-            measuring = true;
-            RM_HIP(ctx->d_tile_cost.reserve(n_tiles));
-            RM_HIP(ctx->d_tile_order.reserve(n_tiles));
+            pend.measuring = true;
+            RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
+            RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles));
             fr.tile_cost = ctx->d_tile_cost.ptr;
-        } else {
-            fr.tile_order = ctx->d_tile_order.ptr;
         }
     }
     rmdev::WorkCounters *d_cnt = nullptr;
@@ -164,43 +176,54 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         RM_HIP(ctx->d_counters.reserve(1));
         d_cnt = ctx->d_counters.ptr;
         RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(rmdev::WorkCounters), ctx->stream));
+        pend.counted = true;
     }
-    RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
         if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
                                          ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
+    RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    pend.active = true;
+    return RM_OK;
+}
+
+// Waits for the stream and books the last enqueued frame: kernel times, tile order, work counters.
+int finish_bands(rm_context *ctx) {
+    RM_HIP(hipSetDevice(ctx->device));
     RM_HIP(hipStreamSynchronize(ctx->stream));
+    const rm_context::Pending pend = ctx->pending;
+    ctx->pending = rm_context::Pending{};
+    if (!pend.active) return RM_OK;
     float ms_trace = 0.0f, ms_resolve = 0.0f;
     RM_HIP(hipEventElapsedTime(&ms_trace, ctx->ev[0], ctx->ev[1]));
     RM_HIP(hipEventElapsedTime(&ms_resolve, ctx->ev[1], ctx->ev[2]));
-    if (measuring) {
-        std::vector<uint32_t> cost(n_tiles), order(n_tiles);
-        RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (pend.measuring) {
+        std::vector<uint32_t> cost(pend.n_tiles), order(pend.n_tiles);
+        RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, pend.n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, order.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, order.data(), pend.n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
         ctx->order_ready = true;
     }
     ctx->last = rm_counters{};
-    ctx->last.tiles_by_cost = (scheduled && !measuring) ? 1u : 0u;
+    ctx->last.tiles_by_cost = pend.by_cost ? 1u : 0u;
     ctx->last.kernel_ms = ms_trace;
     ctx->last.resolve_ms = ms_resolve;
     ctx->last.prims = ctx->program.n_prims;
     ctx->last.lattice_prims = ctx->program.lattice_prims;
     ctx->last.flops_per_sdf = ctx->program.flops_per_sdf;
     ctx->last.compile_ms = ctx->module.compile_seconds * 1e3;
-    ctx->last.compiled_kernel = compiled ? 1u : 0u;
-    if (ctx->counting) {
+    ctx->last.compiled_kernel = pend.compiled ? 1u : 0u;
+    if (pend.counted) {
         rmdev::WorkCounters h{};
-        RM_HIP(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
+        RM_HIP(hipMemcpy(&h, ctx->d_counters.ptr, sizeof h, hipMemcpyDeviceToHost));
         ctx->last.sdf_calls = h.sdf_calls;
         ctx->last.march_steps = h.march_steps;
         ctx->last.rays = h.rays;
@@ -209,6 +232,12 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
         ctx->last.flops_executed = h.flops;
     }
     return RM_OK;
+}
+
+// Trace + resolve of the given bands into device buffers; synchronises the stream.
+int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8) {
+    if (int rc = enqueue_bands(ctx, rows, d_f32, d_rgba8, true)) return rc;
+    return finish_bands(ctx);
 }
 
 }  // namespace
@@ -233,7 +262,8 @@ int rm_create(int device, rm_context **out) {
     rm_context *ctx = new (std::nothrow) rm_context();
     if (!ctx) return fail(RM_ERR_INVALID, "rm_create: out of host memory");
     ctx->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    ctx->stream = ctx->own_stream;
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
         rm_destroy(ctx);
@@ -256,7 +286,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RM_OK;
 }
@@ -329,6 +359,26 @@ int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, ui
     if (int rc = check_ready(ctx)) return rc;
     if (!rows) return fail(RM_ERR_INVALID, "rm_render_device: null rows");
     return render_bands(ctx, *rows, device_f32, device_rgba8);
+}
+
+int rm_enqueue_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_device: null rows");
+    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false);
+}
+
+int rm_wait(rm_context *ctx) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    return finish_bands(ctx);
+}
+
+int rm_set_stream(rm_context *ctx, void *hip_stream) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->pending = rm_context::Pending{};
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RM_OK;
 }
 
 int rm_render_rgba8(rm_context *ctx, uint8_t *host_image) {

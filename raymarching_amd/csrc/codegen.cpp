@@ -132,10 +132,10 @@ struct Emitter {
             flops += r.a[1] * flops_of_kind(r.a[2]);
         } else if (track) {   // REC_LATTICE
             std::snprintf(buf, sizeof buf,
-                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<true, false>(lds.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], evals_unused[n]);\n",
-                          r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
+                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<true, false>(lds.lattice + %uu, (ConstIndex)sc.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], evals_unused[n]);\n",
+                          r.a[1], r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
         } else {
-            std::snprintf(buf, sizeof buf, "    lattice_sd<COUNT, NP>(lds.lattice + %uu, %uu, %uu, p, %s, work);\n", r.a[1], r.a[0], r.prim,
+            std::snprintf(buf, sizeof buf, "    lattice_sd<COUNT, NP>(lds.lattice + %uu, (ConstIndex)sc.lattice + %uu, %uu, %uu, p, %s, work);\n", r.a[1], r.a[1], r.a[0], r.prim,
                           acc(depth).c_str());
         }
         s += buf;

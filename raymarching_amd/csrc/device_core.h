@@ -237,14 +237,28 @@ __device__ __forceinline__ void axis_range(const uint32_t *tab, int n, float p, 
 
 // One row of crosses: two axis terms fixed (d1, d2 in axis order), the third axis running over all
 // n centres of the level.  AXIS = the running axis; the operands keep their x, y, z places in the
-// reference's sum.  `fixed_ones` = digit masks of the two fixed indices, or-ed.
+// reference's sum.  `fixed_ones` = digit masks of the two fixed indices, or-ed.  (Reading the row's
+// tables through the scalar unit instead of LDS was measured slower: 1.15 vs 1.05 ms per default frame.)
 template <int AXIS>
-__device__ __forceinline__ float lattice_row(const uint32_t *T, const uint32_t *ONES, int n, float pt, float h, float d1,
-                                             float d2, uint32_t fixed_ones, float run) {
-    for (int k = 0; k < n; ++k) {
-        const float t = axis_term(T, k, pt, h);
-        const float v = -(AXIS == 0 ? cross_value(t, d1, d2) : (AXIS == 1 ? cross_value(d1, t, d2) : cross_value(d1, d2, t)));
-        run = (ONES[k] & fixed_ones) ? run : __builtin_fmaxf(run, v);
+__device__ __forceinline__ float lattice_cell(float coord, uint32_t ones, float pt, float h, float d1, float d2,
+                                              uint32_t fixed_ones, float run) {
+    const float t = __builtin_fabsf(pt - coord) - h;
+    const float v = -(AXIS == 0 ? cross_value(t, d1, d2) : (AXIS == 1 ? cross_value(d1, t, d2) : cross_value(d1, d2, t)));
+    return (ones & fixed_ones) ? run : __builtin_fmaxf(run, v);
+}
+
+template <int AXIS>
+__device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONES, int n, float pt, float h, float d1, float d2,
+                                             uint32_t fixed_ones, float run) {
+    if (n == 1) return lattice_cell<AXIS>(T[0], ONES[0], pt, h, d1, d2, fixed_ones, run);
+    // n is a power of 3: three table entries are read together, then evaluated, so the loop waits for
+    // LDS once per three crosses (batches of nine measured slower: 1.19 vs 1.07 ms per default frame)
+    for (int k = 0; k < n; k += 3) {
+        const float c0 = T[k], c1 = T[k + 1], c2 = T[k + 2];
+        const uint32_t o0 = ONES[k], o1 = ONES[k + 1], o2 = ONES[k + 2];
+        run = lattice_cell<AXIS>(c0, o0, pt, h, d1, d2, fixed_ones, run);
+        run = lattice_cell<AXIS>(c1, o1, pt, h, d1, d2, fixed_ones, run);
+        run = lattice_cell<AXIS>(c2, o2, pt, h, d1, d2, fixed_ones, run);
     }
     return run;
 }
@@ -256,18 +270,22 @@ __device__ __forceinline__ int nearest_index(float p, float origin, float inv_sp
 }
 
 template <bool TRACK, bool COUNT>
-__device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels, uint32_t first_row, V3 p, float &acc,
-                                             uint32_t &acc_prim, uint32_t &n_evals) {
-    const float bound = __builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __uint_as_float(w[2]);
+__device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, uint32_t levels, uint32_t first_row, V3 p,
+                                             float &acc, uint32_t &acc_prim, uint32_t &n_evals) {
+    // w: the lattice block in LDS (lookups at per-lane indices); g: the same block in global memory,
+    // read through the scalar unit (header fields, whole rows)
+    const ConstFloats gf = (ConstFloats)g;
+    const float bound = __builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + gf[2];
     const float eps = 2e-6f * bound;   // > 8x the worst rounding of dx + dy + dz - min - max at this magnitude
     float run = acc;
     int n = 1;
     for (uint32_t l = 0; l < levels; ++l, n *= 3) {
-        const float h = __uint_as_float(w[kLatHalf + l]);
+        const float h = gf[kLatHalf + l];
         if (!(run < h * 1.00001f + eps)) break;   // no cross this fine can beat the running value
         const float tau = eps - run;
-        const float inv = __uint_as_float(w[kLatInvSpacing + l]);
-        const uint32_t *X = w + w[kLatOffset + l];
+        const float inv = gf[kLatInvSpacing + l];
+        const uint32_t offset = g[kLatOffset + l];
+        const uint32_t *X = w + offset;
         const uint32_t *Y = X + n;
         const uint32_t *Z = Y + n;
         const uint32_t *ONES = Z + n;
@@ -278,23 +296,23 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
             // be in range.  (Tables are evenly spaced to 1 % of a step, and the three axes' spacings
             // agree to 1 %: whenever some centre is in range, it is the one the estimate picks; when
             // none is, the pick fails the test.)  One round of independent loads, no scans.
-            const int ix = nearest_index(p.x, __uint_as_float(w[kLatOrigin + 3 * l]), inv, n - 1);
-            const int iy = nearest_index(p.y, __uint_as_float(w[kLatOrigin + 3 * l + 1]), inv, n - 1);
-            const int iz = nearest_index(p.z, __uint_as_float(w[kLatOrigin + 3 * l + 2]), inv, n - 1);
+            const int ix = nearest_index(p.x, gf[kLatOrigin + 3 * l], inv, n - 1);
+            const int iy = nearest_index(p.y, gf[kLatOrigin + 3 * l + 1], inv, n - 1);
+            const int iz = nearest_index(p.z, gf[kLatOrigin + 3 * l + 2], inv, n - 1);
             const float dx = axis_term(X, ix, p.x, h), dy = axis_term(Y, iy, p.y, h), dz = axis_term(Z, iz, p.z, h);
             const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
             const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
             // two zero offsets at one subdivision step: no such sub-cube
             if (bx && by && !(ox & oy)) {
-                run = lattice_row<2>(Z, ONES, n, p.z, h, dx, dy, ox | oy, run);
+                run = lattice_row<2>((const float *)Z, ONES, n, p.z, h, dx, dy, ox | oy, run);
                 if (COUNT) n_evals += n;
             }
             if (bx && bz && !(ox & oz)) {
-                run = lattice_row<1>(Y, ONES, n, p.y, h, dx, dz, ox | oz, run);
+                run = lattice_row<1>((const float *)Y, ONES, n, p.y, h, dx, dz, ox | oz, run);
                 if (COUNT) n_evals += n;
             }
             if (by && bz && !(oy & oz)) {
-                run = lattice_row<0>(X, ONES, n, p.x, h, dy, dz, oy | oz, run);
+                run = lattice_row<0>((const float *)X, ONES, n, p.x, h, dy, dz, oy | oz, run);
                 if (COUNT) n_evals += n;
             }
             continue;
@@ -309,7 +327,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int j = loy; j <= hiy; ++j) {
                     const uint32_t oi = ONES[i], oj = ONES[j];
                     if (oi & oj) continue;
-                    run = lattice_row<2>(Z, ONES, n, p.z, h, axis_term(X, i, p.x, h), axis_term(Y, j, p.y, h), oi | oj, run);
+                    run = lattice_row<2>((const float *)Z, ONES, n, p.z, h, axis_term(X, i, p.x, h), axis_term(Y, j, p.y, h), oi | oj, run);
                     if (COUNT) n_evals += n;
                 }
         }
@@ -318,7 +336,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oi = ONES[i], ok = ONES[k];
                     if (oi & ok) continue;
-                    run = lattice_row<1>(Y, ONES, n, p.y, h, axis_term(X, i, p.x, h), axis_term(Z, k, p.z, h), oi | ok, run);
+                    run = lattice_row<1>((const float *)Y, ONES, n, p.y, h, axis_term(X, i, p.x, h), axis_term(Z, k, p.z, h), oi | ok, run);
                     if (COUNT) n_evals += n;
                 }
         }
@@ -327,7 +345,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
                 for (int k = loz; k <= hiz; ++k) {
                     const uint32_t oj = ONES[j], ok = ONES[k];
                     if (oj & ok) continue;
-                    run = lattice_row<0>(X, ONES, n, p.x, h, axis_term(Y, j, p.y, h), axis_term(Z, k, p.z, h), oj | ok, run);
+                    run = lattice_row<0>((const float *)X, ONES, n, p.x, h, axis_term(Y, j, p.y, h), axis_term(Z, k, p.z, h), oj | ok, run);
                     if (COUNT) n_evals += n;
                 }
         }
@@ -338,12 +356,12 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, uint32_t levels,
 
 // lattice_fold at NP points with the work booked (distance-only walk)
 template <bool COUNT, int NP>
-__device__ __forceinline__ void lattice_sd(const uint32_t *w, uint32_t levels, uint32_t first_row, const V3 (&p)[NP],
-                                           float (&acc)[NP], Work (&work)[NP]) {
+__device__ __forceinline__ void lattice_sd(const uint32_t *w, ConstIndex g, uint32_t levels, uint32_t first_row,
+                                           const V3 (&p)[NP], float (&acc)[NP], Work (&work)[NP]) {
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
         uint32_t evals = 0, no_prim = kNoPrim;
-        lattice_fold<false, COUNT>(w, levels, first_row, p[n], acc[n], no_prim, evals);
+        lattice_fold<false, COUNT>(w, g, levels, first_row, p[n], acc[n], no_prim, evals);
         if (COUNT) {
             work[n].evals += evals;
             work[n].flops += kFlopsCross * evals;

@@ -62,7 +62,7 @@ struct InterpretedScene {
                 }
             } break;
             case REC_LATTICE | FOLD_NEG | FOLD_MAX: {
-                lattice_sd<COUNT, NP>(lds.lattice + cur[1], cur[0], cur[7], p, acc, work);
+                lattice_sd<COUNT, NP>(lds.lattice + cur[1], (ConstIndex)sc.lattice + cur[1], cur[0], cur[7], p, acc, work);
             } break;
             default: {   // REC_RUN with any fold
                 const uint32_t first = cur[0], count = cur[1], kind = cur[2];
@@ -139,7 +139,7 @@ struct InterpretedScene {
             } else if (code == REC_LATTICE) {
     #pragma unroll
                 for (int n = 0; n < NP; ++n)
-                    lattice_fold<true, false>(lds.lattice + r[1], r[0], r[7], p[n], acc[n], accp[n], evals_unused[n]);
+                    lattice_fold<true, false>(lds.lattice + r[1], (ConstIndex)sc.lattice + r[1], r[0], r[7], p[n], acc[n], accp[n], evals_unused[n]);
             } else if (code == REC_PUSH) {
                 uint32_t *slot = lds.park + r[0] * (2u * kMaxPts * 256u) + threadIdx.x;
     #pragma unroll

@@ -44,3 +44,45 @@ def assemble(stacked, height, band_rows):
     world, local_rows, width, ch = stacked.shape
     g = stacked.view(world, local_rows // band_rows, band_rows, width, ch).permute(1, 0, 2, 3, 4)
     return g.reshape(-1, width, ch)[:height]
+
+
+class FrameGatherer:
+    """Gathers one frame's shards to rank 0 without blocking the host, into buffers allocated once.
+
+    start(shard) issues the gather (asynchronously: the collective is ordered after the work queued so
+    far on the current stream) and, on rank 0, queues the de-interleaving copy behind it; the returned
+    handle's wait() makes the current stream wait for the collective, which is what a rank needs before
+    it overwrites `shard` with the next frame.  frame() is rank 0's assembled [height, W, C] tensor, valid
+    once the stream has reached the copy.
+    """
+
+    def __init__(self, shard, height, band_rows, world, rank):
+        import torch
+
+        self.height, self.band_rows, self.world, self.rank = height, band_rows, world, rank
+        self.stack = self.out = None
+        if world > 1 and rank == 0:
+            self.stack = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
+            self.parts = list(self.stack.unbind(0))
+            self.out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        self.single = None
+
+    def start(self, shard):
+        import torch.distributed as dist
+
+        if self.world == 1:
+            self.single = shard
+            return None
+        work = dist.gather(shard, self.parts if self.rank == 0 else None, dst=0, async_op=True)
+        if self.rank == 0:
+            work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
+            local_rows, width, ch = self.stack.shape[1:]
+            nb = local_rows // self.band_rows
+            src = self.stack.view(self.world, nb, self.band_rows, width, ch).permute(1, 0, 2, 3, 4)
+            self.out.view(nb, self.world, self.band_rows, width, ch).copy_(src)
+        return work
+
+    def frame(self):
+        if self.world == 1:
+            return self.single[:self.height]
+        return self.out[:self.height] if self.rank == 0 else None

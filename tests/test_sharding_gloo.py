@@ -30,11 +30,20 @@ def _worker(rank, world, port, height, width, band_rows, out_path):
             if r0 < height:
                 shard[i * band_rows: i * band_rows + (r1 - r0)] = full[r0:r1]
         frame = sharding.gather_frame(shard, height, band_rows, world, rank)
+        # the pipelined path of bench.py: two frames in flight through two gatherers
+        gatherers = [sharding.FrameGatherer(shard, height, band_rows, world, rank) for _ in range(2)]
+        shards = [shard.clone(), (255 - shard)]
+        works = [g.start(sh) for g, sh in zip(gatherers, shards)]
+        for w in works:
+            if w is not None:
+                w.wait()
         if rank == 0:
             assert frame.shape == full.shape
-            np.save(out_path, (frame == full).all().item())
+            ok = (frame == full).all().item()
+            ok = ok and (gatherers[0].frame() == full).all().item() and (gatherers[1].frame() == 255 - full).all().item()
+            np.save(out_path, ok)
         else:
-            assert frame is None
+            assert frame is None and gatherers[0].frame() is None
     finally:
         dist.destroy_process_group()
 
