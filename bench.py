@@ -44,7 +44,7 @@ import torch.distributed as dist  # noqa: E402
 import raymarching_amd as rm  # noqa: E402
 from raymarching_amd import sharding  # noqa: E402
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet (an FMA every issue slot); DESIGN.md has the non-fused limit
+FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet: an FMA in every issue slot; code without fusable multiply-adds tops out near half of it
 WORKLOADS = {
     # name: (scene file, params overrides, description)
     "default": ("default.txt", dict(), "configs[1]: shipped scene (Menger iterations 3), 1024x768, SSAA 3x3, 2 lights"),
@@ -284,7 +284,7 @@ def main():
                 "prim_evals_per_sdf_call": round(cnt["prim_evals"] / max(1, cnt["sdf_calls"]), 2),
                 "brute_force_equivalent": {"flops_per_sdf_call": cnt["flops_per_sdf"], "flops_per_frame": int(total_algo),
                                            "tflops": round(local_algo / (kernel_ms * 1e-3) / 1e12, 2)},
-                "note": "peak is the FMA-every-slot datasheet figure; this path has no multiply-adds to fuse (DESIGN.md)",
+                "note": "peak is the FMA-every-slot datasheet figure; this path has no multiply-adds to fuse, its instruction mix tops out near 80 TFLOP/s (tools/valu_bench.hip)",
             },
             "frame_ms": round(ms_per_step, 4),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),

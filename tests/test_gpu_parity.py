@@ -276,3 +276,41 @@ def test_cost_ordered_tiles_render_the_same_frame(rm, renderer):
         assert natural.tobytes() == first.tobytes()
     finally:
         renderer.set_tile_scheduling(True)
+
+
+def test_queued_frames_on_caller_streams_equal_synchronous_render(rm):
+    """rm_enqueue_device / rm_wait / rm_set_stream: frames of two contexts in flight on two torch streams."""
+    import torch
+    p = rm.default_params(width=256, height=160, kernel=2)
+    scene = rm.Scene(scene_path("default.txt"))
+    rows = rm.binding.Rows(160, 0, 1, 1)
+    ctxs, streams, bufs = [], [], []
+    try:
+        for _ in range(2):
+            r = rm.Renderer(0)
+            r.set_params(p)
+            r.set_scene(scene)
+            ctxs.append(r)
+            streams.append(torch.cuda.Stream())
+            bufs.append(torch.zeros((160, 256, 4), dtype=torch.float32, device="cuda"))
+        ref = ctxs[0].render_f32()                                 # synchronous; also times the tiles
+        ctxs[1].render_device(rows, bufs[1].data_ptr(), None)
+        for r, st in zip(ctxs, streams):
+            r.set_stream(st.cuda_stream)
+        for rep in range(3):
+            for r, st, b in zip(ctxs, streams, bufs):
+                with torch.cuda.stream(st):
+                    b.zero_()                                      # ordered before the kernels: same stream
+                    r.enqueue_device(rows, b.data_ptr(), None)
+        for r in ctxs:
+            r.wait()
+            c = r.counters()
+            assert c["kernel_ms"] > 0 and c["compiled_kernel"] == 1 and c["tiles_by_cost"] == 1
+        for b in bufs:
+            assert np.array_equal(b.cpu().numpy(), ref)
+        for r in ctxs:
+            r.set_stream(None)
+        assert np.array_equal(ctxs[0].render_f32(), ref)
+    finally:
+        for r in ctxs:
+            r.close()
