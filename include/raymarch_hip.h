@@ -158,6 +158,13 @@ int rm_set_stream(rm_context *ctx, void *hip_stream);
  * the device evaluator of Body::List::SDF (body.cpp:66-111) for parity tests. */
 int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim);
 
+/* The same, plus the value of the distance-only evaluator that the march loop, the gradient taps
+ * and the shadow rays use (it skips primitives that provably cannot change the result: hulls of
+ * long runs, rejected spheres, bounded nested lists, lattice crosses out of range).  The two
+ * distances must be equal bit for bit; parity tests check that at arbitrary points. */
+int rm_eval_sdf_both(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim,
+                     float *host_sd_march);
+
 /*
  * How runs of primitives are evaluated (no counterpart in the reference, whose two back-ends
  * always visit every primitive).  Both give bit-identical frames.

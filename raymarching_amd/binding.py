@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -80,6 +80,7 @@ def lib():
     L.rm_wait.argtypes = [vp]
     L.rm_set_stream.argtypes = [vp, vp]
     L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.rm_eval_sdf_both.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
     L.rm_set_counting.argtypes = [vp, C.c_int]
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
@@ -225,6 +226,16 @@ class Renderer:
         prim = np.zeros(len(xyz), np.uint32)
         _check(lib().rm_eval_sdf(self._h, xyz.ctypes.data, len(xyz), sd.ctypes.data, prim.ctypes.data), "rm_eval_sdf")
         return sd, prim
+
+    def eval_sdf_both(self, xyz):
+        """(sd, prim, sd_march): the colour-tracking evaluator's result and the distance-only evaluator's."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        sd = np.zeros(len(xyz), np.float32)
+        sd_march = np.zeros(len(xyz), np.float32)
+        prim = np.zeros(len(xyz), np.uint32)
+        _check(lib().rm_eval_sdf_both(self._h, xyz.ctypes.data, len(xyz), sd.ctypes.data, prim.ctypes.data, sd_march.ctypes.data),
+               "rm_eval_sdf_both")
+        return sd, prim, sd_march
 
     def set_kernel_mode(self, compiled):
         """True (default): kernels generated and compiled per scene; False: the record-walking kernel.

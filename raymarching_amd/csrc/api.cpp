@@ -405,22 +405,37 @@ int rm_render_f32(rm_context *ctx, float *host_image) {
     return RM_OK;
 }
 
-int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim) {
+namespace {
+
+int eval_points(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim, float *host_sd_march) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (!ctx->have_scene) return fail(RM_ERR_STATE, "rm_set_scene has not been called");
     if (n == 0) return RM_OK;
     if (!host_xyz || !host_sd || !host_prim) return fail(RM_ERR_INVALID, "rm_eval_sdf: null argument");
     RM_HIP(hipSetDevice(ctx->device));
     RM_HIP(ctx->d_points.reserve((size_t)n * 3));
-    RM_HIP(ctx->d_sd.reserve(n));
+    RM_HIP(ctx->d_sd.reserve((size_t)n * 2));
     RM_HIP(ctx->d_prim.reserve(n));
+    float *d_march = host_sd_march ? ctx->d_sd.ptr + n : nullptr;
     RM_HIP(hipMemcpyAsync(ctx->d_points.ptr, host_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (ctx->module.loaded()) RM_HIP(rmdev::launch_eval_sdf_module(ctx->module, ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
-    else RM_HIP(rmdev::launch_eval_sdf(ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, ctx->stream));
+    if (ctx->module.loaded()) RM_HIP(rmdev::launch_eval_sdf_module(ctx->module, ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, d_march, ctx->stream));
+    else RM_HIP(rmdev::launch_eval_sdf(ctx->scene, ctx->d_points.ptr, n, ctx->d_sd.ptr, ctx->d_prim.ptr, d_march, ctx->stream));
     RM_HIP(hipMemcpyAsync(host_sd, ctx->d_sd.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipMemcpyAsync(host_prim, ctx->d_prim.ptr, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (host_sd_march) RM_HIP(hipMemcpyAsync(host_sd_march, d_march, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
     return RM_OK;
+}
+
+}  // namespace
+
+int rm_eval_sdf(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim) {
+    return eval_points(ctx, host_xyz, n, host_sd, host_prim, nullptr);
+}
+
+int rm_eval_sdf_both(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim, float *host_sd_march) {
+    if (!host_sd_march) return fail(RM_ERR_INVALID, "rm_eval_sdf_both: null argument");
+    return eval_points(ctx, host_xyz, n, host_sd, host_prim, host_sd_march);
 }
 
 int rm_set_evaluator(rm_context *ctx, int evaluator) {

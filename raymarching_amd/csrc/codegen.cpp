@@ -123,6 +123,11 @@ struct Emitter {
             }
             evals += 1;
             flops += flops_of_code(code);
+        } else if (code == REC_RUN && (r.flags & RUN_CLUSTERED) && !track) {
+            std::snprintf(buf, sizeof buf,
+                          "    fold_run_clustered<%s, %s, %s, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, %uu, %uu, %uu, %uu, %s, p, %s, work);\n",
+                          kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), r.a[0], r.a[1], r.h[0], r.h[1], lit(as_float(r.h[2])).c_str(),
+                          acc(depth).c_str());
         } else if (code == REC_RUN) {
             std::snprintf(buf, sizeof buf,
                           "    fold_run<%s, %s, %s, NP, %s>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, %uu, %uu, p, %s, %s);\n",
@@ -279,7 +284,7 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
                   min_waves, points_per_lane, counting ? "true" : "false");
     s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
-         "        uint32_t *prim) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim);\n}\n";
+         "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n";
     return s;
 }
 

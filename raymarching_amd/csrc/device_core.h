@@ -195,6 +195,88 @@ __device__ __forceinline__ void fold_run_kind(const SceneView &sc, uint32_t flag
     }
 }
 
+// ---- clustered RUN: hulls rule out groups of rows --------------------------------------------
+//
+// Folds that keep small values of the child distance v -- min(s, v) and max(s, -v) -- are left
+// unchanged by every child with v >= need, need = s or -s.  A hull H contains its rows' primitives
+// (per axis: [c - h, c + h] of every row lies inside the hull's interval; spheres: inside the hull
+// sphere), so in exact arithmetic v_row(p) >= v_H(p): sphere distances by the triangle inequality,
+// box and cross distances because each axis term |p - c| - h can only grow when the interval
+// shrinks and max / median are monotone.  The host pads the hulls by 1e-6 relative, and the test
+// leaves eps = 2e-6 x (|p| + the run's magnitude bound), more than 8 times the rounding of either
+// side's few operations at that magnitude (spheres: the margins of sphere_cannot_change).  A
+// hull that fails the test, NaNs included, has its rows evaluated with the plain formula, so the
+// fold's result is that of visiting every row, bit for bit.
+template <uint32_t KIND, bool NEG>
+__device__ __forceinline__ bool hull_needs_rows(const RowWords ra, const RowWords rb, V3 p, float acc, float eps) {
+    const float need = NEG ? -acc : acc;
+    if (KIND == K_SPHERE) return !sphere_cannot_change<false, false>(need, sphere_d2(p, ra[0], ra[1], ra[2]), ra[3]);
+    const float dx = __builtin_fabsf(p.x - ra[0]) - ra[3];
+    const float dy = __builtin_fabsf(p.y - ra[1]) - rb[0];
+    const float dz = __builtin_fabsf(p.z - ra[2]) - rb[1];
+    const float v = (KIND == K_BOX || KIND == K_BOX_ISO) ? __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz) : cross_value(dx, dy, dz);
+    return !(v - eps >= need);
+}
+
+template <uint32_t KIND, bool NEG, bool MAX, int NP, bool COUNT>
+__device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count, uint32_t cfirst,
+                                                   uint32_t sfirst, float magnitude, const V3 (&p)[NP], float (&acc)[NP],
+                                                   Work (&work)[NP]) {
+    static_assert(NEG == MAX, "hulls give lower bounds: only folds that keep small distances can use them");
+    float eps[NP];
+    uint32_t no_prim[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        eps[n] = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + magnitude);
+        no_prim[n] = kNoPrim;
+    }
+    const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
+    const uint32_t n_supers = sfirst != kNoRow ? (n_clusters + kClusterSize - 1u) / kClusterSize : 1u;
+    uint32_t tested = 0, evaluated = 0;
+    for (uint32_t s = 0; s < n_supers; ++s) {
+        uint32_t c0 = 0, c1 = n_clusters;
+        if (sfirst != kNoRow) {
+            const RowWords ha = pa[sfirst + s], hb = pb[sfirst + s];
+            bool need = false;
+#pragma unroll
+            for (int n = 0; n < NP; ++n) need = need || hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n]);
+            tested++;
+            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+            c0 = s * kClusterSize;
+            c1 = c0 + kClusterSize < n_clusters ? c0 + kClusterSize : n_clusters;
+        }
+        for (uint32_t c = c0; c < c1; ++c) {
+            const RowWords ha = pa[cfirst + c], hb = pb[cfirst + c];
+            bool need = false;
+#pragma unroll
+            for (int n = 0; n < NP; ++n) need = need || hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n]);
+            tested++;
+            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+            const uint32_t i0 = c * kClusterSize;
+            const uint32_t rows = i0 + kClusterSize < count ? kClusterSize : count - i0;
+            fold_run<KIND, NEG, MAX, NP, false>(pa, pb, (ConstIndex)0, first + i0, rows, p, acc, no_prim);
+            evaluated += rows;
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            work[n].evals += tested + evaluated;
+            work[n].flops += (tested + evaluated) * flops_of_kind(KIND);
+        }
+    }
+}
+
+// interpreter entry: fold known at run time (one of the two a clustered run can have)
+template <uint32_t KIND, int NP, bool COUNT>
+__device__ __forceinline__ void fold_run_clustered_kind(const SceneView &sc, const RecWords &r, const V3 (&p)[NP],
+                                                        float (&acc)[NP], Work (&work)[NP]) {
+    if (r[6] & FOLD_MAX)
+        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3], r[4], __uint_as_float(r[5]), p, acc, work);
+    else
+        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3], r[4], __uint_as_float(r[5]), p, acc, work);
+}
+
 // ---- LATTICE: a complete Menger lattice of cubic crosses, folded with max(s, -cross) ----------
 //
 // The brute-force fold visits every cross c and keeps max(s, -c(p)), c(p) = dx + dy + dz - min - max

@@ -41,6 +41,10 @@ enum Kind : uint32_t { K_SPHERE = 1, K_BOX = 2, K_CROSS = 3, K_BOX_ISO = 4, K_CR
 
 // fold bits as they sit in Rec::flags (above the 4-bit record code)
 enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u };
+// RUN only: the run's rows are sorted in space and come with bounding hulls (see below)
+constexpr uint32_t RUN_CLUSTERED = 64u;
+constexpr uint32_t kClusterSize = 8;        // rows per cluster, clusters per super-cluster
+constexpr uint32_t kNoRow = 0xffffffffu;
 
 // 32 bytes, wave-uniform, fetched with one scalar load (s_load_dwordx8).
 //   primitive: a = (centre.x, centre.y, centre.z), h = (half.x | radius, half.y, half.z),
@@ -48,6 +52,14 @@ enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u };
 //   RUN:       a = (first row, count, kind) as integers; the primitives of one list and kind,
 //              gathered in depth-first order (a fold may run in any order: ties between equal
 //              distances are broken by depth-first index, which keeps the earlier child)
+//              With RUN_CLUSTERED (folds that keep small values of v: min(s, c) and max(s, -c)):
+//              h = (first cluster hull row, first super-cluster hull row or kNoRow, magnitude bound
+//              as float bits).  The run's rows are sorted along a space-filling curve; every 8
+//              consecutive rows have a hull row -- a primitive of the same kind (sphere, box or
+//              cross with three half sizes) that contains them, so that its distance is a lower
+//              bound of theirs -- and every 8 consecutive hulls a hull of their own.  Hull rows sit
+//              in the same tables, outside every run.  A hull whose distance cannot beat the
+//              accumulator rules out all rows below it.
 //   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
 //   PUSH:      a[0] = slot, a[1] = identity of the list that starts (float bits)
 //   POP:       a[0] = slot

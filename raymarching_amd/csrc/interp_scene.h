@@ -66,6 +66,16 @@ struct InterpretedScene {
             } break;
             default: {   // REC_RUN with any fold
                 const uint32_t first = cur[0], count = cur[1], kind = cur[2];
+                if (cur[6] & RUN_CLUSTERED) {
+                    switch (kind) {
+                    case K_SPHERE: fold_run_clustered_kind<K_SPHERE, NP, COUNT>(sc, cur, p, acc, work); break;
+                    case K_BOX: fold_run_clustered_kind<K_BOX, NP, COUNT>(sc, cur, p, acc, work); break;
+                    case K_CROSS: fold_run_clustered_kind<K_CROSS, NP, COUNT>(sc, cur, p, acc, work); break;
+                    case K_BOX_ISO: fold_run_clustered_kind<K_BOX_ISO, NP, COUNT>(sc, cur, p, acc, work); break;
+                    default: fold_run_clustered_kind<K_CROSS_ISO, NP, COUNT>(sc, cur, p, acc, work); break;
+                    }
+                    break;
+                }
                 if (COUNT) {
     #pragma unroll
                     for (int n = 0; n < NP; ++n) {

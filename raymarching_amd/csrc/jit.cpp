@@ -120,10 +120,10 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
 }
 
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
-                                  uint32_t *prim, hipStream_t stream) {
+                                  uint32_t *prim, float *sd_march, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     SceneView sc_arg = sc;
-    void *args[] = { &sc_arg, &xyz, &n, &sd, &prim };
+    void *args[] = { &sc_arg, &xyz, &n, &sd, &prim, &sd_march };
     return hipModuleLaunchKernel(m.eval_sdf, (n + 255u) / 256u, 1, 1, 256, 1, 1, lds_bytes_of(sc), stream, args, nullptr);
 }
 

@@ -35,6 +35,6 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
 hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
                                WorkCounters *counters, hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
-                                  uint32_t *prim, hipStream_t stream);
+                                  uint32_t *prim, float *sd_march, hipStream_t stream);
 
 }  // namespace rmdev

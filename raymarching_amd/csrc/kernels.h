@@ -25,6 +25,6 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out
 
 // Scene SDF with colour tracking at n points.
 hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd,
-                           uint32_t *prim, hipStream_t stream);
+                           uint32_t *prim, float *sd_march, hipStream_t stream);
 
 }  // namespace rmdev

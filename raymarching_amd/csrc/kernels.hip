@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView s
 }
 
 __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const float *__restrict__ xyz, uint32_t n,
-                                                        float *__restrict__ sd, uint32_t *__restrict__ prim) {
-    eval_sdf_body<InterpretedScene>(sc, xyz, n, sd, prim);
+                                                        float *__restrict__ sd, uint32_t *__restrict__ prim,
+                                                        float *__restrict__ sd_march) {
+    eval_sdf_body<InterpretedScene>(sc, xyz, n, sd, prim, sd_march);
 }
 
 // render.cpp:103-119: total += colour over i (outer, x) then j (inner, y);
@@ -110,10 +111,10 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out
     return hipGetLastError();
 }
 
-hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd, uint32_t *prim,
+hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd, uint32_t *prim, float *sd_march,
                            hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_sdf_kernel, dim3((n + 255u) / 256u), dim3(256), lds_bytes(sc), stream, sc, xyz, n, sd, prim);
+    hipLaunchKernelGGL(eval_sdf_kernel, dim3((n + 255u) / 256u), dim3(256), lds_bytes(sc), stream, sc, xyz, n, sd, prim, sd_march);
     return hipGetLastError();
 }
 

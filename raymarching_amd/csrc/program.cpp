@@ -13,6 +13,7 @@
 // exactly without visiting every cross.
 #include "program.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -277,6 +278,150 @@ struct Compiler {
         std::vector<uint32_t> node, prim;
     };
 
+    // ---- RUN emission, with bounding hulls for long runs --------------------------------------
+
+    struct Row {
+        Float4 a, b;
+        uint32_t prim;
+        uint64_t key;   // position along the space-filling curve
+    };
+
+    static uint64_t spread3(uint32_t v) {   // 21 bits -> every third bit
+        uint64_t x = v & 0x1fffffu;
+        x = (x | x << 32) & 0x1f00000000ffffull;
+        x = (x | x << 16) & 0x1f0000ff0000ffull;
+        x = (x | x << 8) & 0x100f00f00f00f00full;
+        x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+        x = (x | x << 2) & 0x1249249249249249ull;
+        return x;
+    }
+
+    static float round_up(double v) {
+        float f = (float)v;
+        if ((double)f < v) f = std::nextafterf(f, INFINITY);
+        return f;
+    }
+
+    // half sizes of a row on the three axes (spheres: the radius on each)
+    static void extents(uint32_t kind, const Row &r, double h[3]) {
+        const bool one = kind == K_SPHERE || kind == K_BOX_ISO || kind == K_CROSS_ISO;
+        h[0] = r.a.w;
+        h[1] = one ? r.a.w : r.b.x;
+        h[2] = one ? r.a.w : r.b.y;
+    }
+
+    // Hull of rows[i0, i1): a primitive of the run's kind (three half sizes) that contains them all,
+    // padded by 1e-6 relative so that the rounding of its own centre and sizes cannot let a row stick out.
+    static Row hull_of(uint32_t kind, const std::vector<Row> &rows, size_t i0, size_t i1, const std::vector<Row> *members = nullptr,
+                       size_t m0 = 0, size_t m1 = 0) {
+        // `members`: the primitives below (for hulls of hulls, the rows the child hulls stand for)
+        const std::vector<Row> &prim = members ? *members : rows;
+        const size_t p0 = members ? m0 : i0, p1 = members ? m1 : i1;
+        double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = p0; i < p1; i++) {
+            double h[3];
+            extents(kind, prim[i], h);
+            const double c[3] = { prim[i].a.x, prim[i].a.y, prim[i].a.z };
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::fmin(lo[k], c[k] - h[k]);
+                hi[k] = std::fmax(hi[k], c[k] + h[k]);
+            }
+        }
+        Row out{};
+        const float cf[3] = { (float)((lo[0] + hi[0]) / 2), (float)((lo[1] + hi[1]) / 2), (float)((lo[2] + hi[2]) / 2) };
+        out.a = Float4{ cf[0], cf[1], cf[2], 0.0f };
+        if (kind == K_SPHERE) {
+            double radius = 0.0;
+            for (size_t i = p0; i < p1; i++) {
+                const double dx = (double)prim[i].a.x - cf[0], dy = (double)prim[i].a.y - cf[1], dz = (double)prim[i].a.z - cf[2];
+                radius = std::fmax(radius, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)prim[i].a.w);
+            }
+            out.a.w = round_up(radius * (1.0 + 1e-6) + 1e-30);
+        } else {
+            float hf[3];
+            for (int k = 0; k < 3; k++) {
+                const double h = std::fmax(hi[k] - (double)cf[k], (double)cf[k] - lo[k]);
+                hf[k] = round_up(h * (1.0 + 1e-6) + 1e-6 * std::fabs((double)cf[k]) + 1e-30);
+            }
+            out.a.w = hf[0];
+            out.b = Float4{ hf[1], hf[2], 0.0f, 0.0f };
+        }
+        (void)i0; (void)i1;
+        return out;
+    }
+
+    void push_row(const Row &r) {
+        out.pa.push_back(r.a);
+        out.pb.push_back(r.b);
+        out.row_prim.push_back(r.prim);
+    }
+
+    void emit_run(uint32_t kind, const Bucket &bk, uint32_t fold) {
+        std::vector<Row> rows(bk.node.size());
+        for (size_t i = 0; i < rows.size(); i++) {
+            halves(nodes[bk.node[i]], rows[i].a, rows[i].b);
+            rows[i].prim = bk.prim[i];
+        }
+        Rec r = {};
+        r.a[1] = (uint32_t)rows.size(); r.a[2] = kind;
+        r.flags = REC_RUN | fold;
+        out.run_prims += (uint32_t)rows.size();
+        // hulls bound distances from below: of use to the folds that keep small distances
+        const bool keeps_small = fold == 0u || fold == (FOLD_MAX | FOLD_NEG);
+        bool finite = true;
+        double magnitude = 0.0;
+        for (const Row &row : rows) {
+            double h[3];
+            extents(kind, row, h);
+            const double c[3] = { row.a.x, row.a.y, row.a.z };
+            for (int k = 0; k < 3; k++) {
+                finite = finite && std::isfinite(c[k]) && std::isfinite(h[k]) && h[k] >= 0.0;
+                magnitude = std::fmax(magnitude, std::fabs(c[k]) + h[k]);
+            }
+        }
+        if (use_lattice && keeps_small && finite && rows.size() >= 2 * kClusterSize) {
+            // sort along a Morton curve over the centres' bounding box
+            double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (const Row &row : rows) {
+                const double c[3] = { row.a.x, row.a.y, row.a.z };
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::fmin(lo[k], c[k]);
+                    hi[k] = std::fmax(hi[k], c[k]);
+                }
+            }
+            for (Row &row : rows) {
+                const double c[3] = { row.a.x, row.a.y, row.a.z };
+                uint32_t q[3];
+                for (int k = 0; k < 3; k++) {
+                    const double span = hi[k] - lo[k];
+                    q[k] = span > 0.0 ? (uint32_t)std::fmin(2097151.0, (c[k] - lo[k]) / span * 2097151.0) : 0u;
+                }
+                row.key = spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2;
+            }
+            std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.key < y.key; });
+            const size_t n_clusters = (rows.size() + kClusterSize - 1) / kClusterSize;
+            std::vector<Row> clusters(n_clusters);
+            for (size_t c = 0; c < n_clusters; c++)
+                clusters[c] = hull_of(kind, rows, c * kClusterSize, std::min(rows.size(), (c + 1) * kClusterSize));
+            r.h[0] = (uint32_t)out.pa.size();
+            for (const Row &c : clusters) push_row(c);
+            r.h[1] = kNoRow;
+            if (n_clusters >= 2 * kClusterSize) {
+                r.h[1] = (uint32_t)out.pa.size();
+                const size_t n_supers = (n_clusters + kClusterSize - 1) / kClusterSize;
+                for (size_t s = 0; s < n_supers; s++) {
+                    const size_t m0 = s * kClusterSize * kClusterSize, m1 = std::min(rows.size(), (s + 1) * kClusterSize * kClusterSize);
+                    push_row(hull_of(kind, clusters, 0, 0, &rows, m0, m1));
+                }
+            }
+            r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
+            r.flags |= RUN_CLUSTERED;
+        }
+        r.a[0] = (uint32_t)out.pa.size();
+        for (const Row &row : rows) push_row(row);
+        out.recs.push_back(r);
+    }
+
     // Compiles the children of the list at nodes[list_at]; cursor is on its first child.
     //
     // min and max are commutative and associative on floats, so the children after the first may
@@ -331,18 +476,7 @@ struct Compiler {
         for (uint32_t kind = K_SPHERE; kind <= K_CROSS_ISO; kind++) {
             const Bucket &bk = buckets[kind];
             if (bk.node.size() >= kRunMin) {
-                Rec r = {};
-                r.a[0] = (uint32_t)out.pa.size(); r.a[1] = (uint32_t)bk.node.size(); r.a[2] = kind;
-                r.flags = REC_RUN | fold_rest;
-                out.recs.push_back(r);
-                out.run_prims += (uint32_t)bk.node.size();
-                for (size_t i = 0; i < bk.node.size(); i++) {
-                    Float4 a, b;
-                    halves(nodes[bk.node[i]], a, b);
-                    out.pa.push_back(a);
-                    out.pb.push_back(b);
-                    out.row_prim.push_back(bk.prim[i]);
-                }
+                emit_run(kind, bk, fold_rest);
             } else {
                 for (size_t i = 0; i < bk.node.size(); i++) emit_single(nodes[bk.node[i]], bk.prim[i], fold_rest);
             }

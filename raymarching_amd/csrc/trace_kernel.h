@@ -233,7 +233,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 
 template <class Scene>
 __device__ __forceinline__ void eval_sdf_body(const SceneView &sc, const float *__restrict__ xyz, uint32_t n,
-                                              float *__restrict__ sd, uint32_t *__restrict__ prim) {
+                                              float *__restrict__ sd, uint32_t *__restrict__ prim, float *__restrict__ sd_march) {
     const Lds lds = stage_lds(sc);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t tt = t < n ? t : n - 1;   // every lane walks the scene (nested lists park through LDS)
@@ -244,6 +244,12 @@ __device__ __forceinline__ void eval_sdf_body(const SceneView &sc, const float *
     if (t < n) {
         sd[t] = d[0];
         prim[t] = pr[0];
+    }
+    if (sd_march) {   // the distance-only walker the march loop uses (bounds, rejection tests and all)
+        float dm[1];
+        Work work[1] = {};
+        Scene::template sd<1, false>(sc, lds, p, dm, work);
+        if (t < n) sd_march[t] = dm[0];
     }
 }
 

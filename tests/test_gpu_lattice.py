@@ -48,7 +48,8 @@ def test_lattice_sdf_bitwise(rm, oracle, renderer, levels, pos, size, n_pts):
         renderer.set_evaluator(lattice)
         try:
             renderer.set_scene(rm.Scene(text=text))
-            sd, prim = renderer.eval_sdf(pts)
+            sd, prim, sd_march = renderer.eval_sdf_both(pts)
+            assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
         finally:
             renderer.set_evaluator(True)
         bad = np.flatnonzero(sd.view(np.uint32) != osd.view(np.uint32))
@@ -74,7 +75,8 @@ def test_near_miss_lists_are_not_lattices_and_stay_exact(rm, oracle, renderer):
         onodes = [oracle.Node(n.type, n.mode, n.child_count, n.center, n.size, n.color) for n in nodes]
         osd, _ = oracle.Scene(nodes=onodes).sdf(pts)
         renderer.set_scene_raw(nodes, lights, ident, 1.0)
-        sd, _ = renderer.eval_sdf(pts)
+        sd, _, sd_march = renderer.eval_sdf_both(pts)
+        assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
         assert sd.tobytes() == osd.tobytes()
 
     def copy(nodes):
@@ -145,7 +147,8 @@ def test_closeup6_points_and_tiny_frame(rm, oracle, renderer):
     renderer.set_scene(prod)
     rng = np.random.default_rng(6)
     pts = sponge_points(rng, 96, (0, 10, -50), 20.0)
-    sd, _ = renderer.eval_sdf(pts)
+    sd, _, sd_march = renderer.eval_sdf_both(pts)
+    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
     osd, _ = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     kw = dict(width=6, height=4, kernel=1)
@@ -167,7 +170,8 @@ def test_synthetic1024_frame_bit_identical(rm, oracle, renderer):
     cpu, _ = orc.render(oracle.default_params(**kw))
     assert gpu.tobytes() == cpu.tobytes()
     pts = np.random.default_rng(3).uniform([-70, -2, -120], [70, 40, 20], (5000, 3)).astype(np.float32)
-    sd, prim = renderer.eval_sdf(pts)
+    sd, prim, sd_march = renderer.eval_sdf_both(pts)
+    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
     osd, orgb = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)

@@ -45,7 +45,8 @@ def test_scene_sdf_bitwise(rm, oracle, renderer, name):
     prod, orc = rm.Scene(scene_path(name)), oracle.Scene(scene_path(name))
     renderer.set_scene(prod)
     pts = random_points(np.random.default_rng(1), 20000)
-    sd, prim = renderer.eval_sdf(pts)
+    sd, prim, sd_march = renderer.eval_sdf_both(pts)
+    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
     osd, orgb = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)
@@ -98,7 +99,8 @@ def test_random_trees_all_modes_bitwise(rm, oracle, renderer, seed):
     ident = np.eye(4, dtype=np.float32).T.reshape(-1)
     renderer.set_scene_raw(pnodes, np.zeros((0, 3), np.float32), ident, 1.0)
     pts = rng.uniform(-12, 12, (8000, 3)).astype(np.float32)
-    sd, prim = renderer.eval_sdf(pts)
+    sd, prim, sd_march = renderer.eval_sdf_both(pts)
+    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
     osd, orgb = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     colours = np.array([tuple(p.color) for p in orc.flat_prims()] + [(0, 0, 0)], np.float32)
@@ -251,7 +253,8 @@ def test_ties_between_kinds_keep_the_earlier_child(rm, oracle, renderer, mode, c
     pnodes, onodes = _mk(rm.Node, spec), _mk(oracle.Node, spec)
     renderer.set_scene_raw(pnodes, np.zeros((0, 3), np.float32), np.eye(4, dtype=np.float32).reshape(-1), 1.0)
     pts = np.array(pts, np.float32)
-    sd, prim = renderer.eval_sdf(pts)
+    sd, prim, sd_march = renderer.eval_sdf_both(pts)
+    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
     orc = oracle.Scene(nodes=onodes)
     osd, orgb = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
