@@ -171,7 +171,9 @@ int rm_eval_sdf_both(rm_context *ctx, const float *host_xyz, uint32_t n, float *
  *   RM_EVAL_EXHAUSTIVE  every primitive of the scene is evaluated at every SDF call;
  *   RM_EVAL_LATTICE     (default) lists of cubic crosses that form a complete Menger lattice,
  *                       as Body::MengerSponge generates (body.cpp:114-156), are recognised on
- *                       upload and evaluated exactly by visiting only the crosses that can win.
+ *                       upload and evaluated exactly by visiting only the crosses that can win;
+ *                       other long runs of primitives get bounding hulls (spatially sorted
+ *                       groups of 8 and 64) that rule out groups which cannot win.
  * Takes effect at the next rm_set_scene.
  */
 typedef enum rm_evaluator { RM_EVAL_EXHAUSTIVE = 0, RM_EVAL_LATTICE = 1 } rm_evaluator;
@@ -206,6 +208,18 @@ int rm_set_kernel_mode(rm_context *ctx, int mode);
  */
 typedef enum rm_tile_scheduling { RM_TILES_NATURAL = 0, RM_TILES_BY_COST = 1 } rm_tile_scheduling;
 int rm_set_tile_scheduling(rm_context *ctx, int mode);
+
+/*
+ * The compiled mode's two steps without a device or a context (build checks, inspection):
+ *   rm_kernel_source           writes the HIP source rm_set_scene would generate for the scene into
+ *                              `buffer` (NUL-terminated, truncated to `capacity`) and its full length,
+ *                              without the NUL, into *length; buffer may be NULL to ask for the length;
+ *   rm_kernel_source_compiles  RM_OK if the source compiles for gfx950 with hiprtc; otherwise the
+ *                              compiler's log is in rm_last_error().
+ */
+int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int counting, char *buffer, size_t capacity,
+                     size_t *length);
+int rm_kernel_source_compiles(const char *source);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

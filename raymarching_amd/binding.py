@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -83,6 +83,8 @@ def lib():
     L.rm_eval_sdf_both.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
     L.rm_set_counting.argtypes = [vp, C.c_int]
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
+    L.rm_kernel_source.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rm_kernel_source_compiles.argtypes = [C.c_char_p]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -160,6 +162,21 @@ class Scene:
         f = C.c_float()
         _check(lib().rm_scene_camera(self._h, t.ctypes.data, C.byref(f)), "rm_scene_camera")
         return t, np.float32(f.value)
+
+
+def kernel_source(scene, lattice=True, counting=False):
+    """HIP source of the kernels rm_set_scene generates for `scene` (a Scene); needs no GPU."""
+    arr = scene.nodes()
+    n = C.c_size_t()
+    _check(lib().rm_kernel_source(arr, len(arr), 1 if lattice else 0, int(counting), None, 0, C.byref(n)), "rm_kernel_source")
+    buf = C.create_string_buffer(n.value + 1)
+    _check(lib().rm_kernel_source(arr, len(arr), 1 if lattice else 0, int(counting), buf, n.value + 1, C.byref(n)), "rm_kernel_source")
+    return buf.value.decode()
+
+
+def kernel_source_compiles(source):
+    """Raises RaymarchError with the compiler log unless `source` compiles for gfx950 (hiprtc; needs no GPU)."""
+    _check(lib().rm_kernel_source_compiles(source.encode()), "rm_kernel_source_compiles")
 
 
 class Renderer:

@@ -438,6 +438,28 @@ int rm_eval_sdf_both(rm_context *ctx, const float *host_xyz, uint32_t n, float *
     return eval_points(ctx, host_xyz, n, host_sd, host_prim, host_sd_march);
 }
 
+int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int counting, char *buffer, size_t capacity, size_t *length) {
+    if (!length) return fail(RM_ERR_INVALID, "rm_kernel_source: null length pointer");
+    std::string why;
+    rmdev::HostProgram prog;
+    if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_kernel_source: " + why);
+    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, counting != 0);
+    *length = src.size();
+    if (buffer && capacity) {
+        const size_t n = src.size() < capacity - 1 ? src.size() : capacity - 1;
+        std::memcpy(buffer, src.data(), n);
+        buffer[n] = '\0';
+    }
+    return RM_OK;
+}
+
+int rm_kernel_source_compiles(const char *source) {
+    if (!source) return fail(RM_ERR_INVALID, "rm_kernel_source_compiles: null source");
+    std::string log;
+    if (!rmdev::check_scene_source(source, log)) return fail(RM_ERR_HIP, log);
+    return RM_OK;
+}
+
 int rm_set_evaluator(rm_context *ctx, int evaluator) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (evaluator != RM_EVAL_EXHAUSTIVE && evaluator != RM_EVAL_LATTICE)

@@ -63,6 +63,8 @@ void SceneModule::unload() {
     *this = SceneModule();
 }
 
+bool check_scene_source(const std::string &source, std::string &log) { return build_code_object(source, log) != nullptr; }
+
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
     out.unload();
     CodeObject code;

@@ -32,6 +32,9 @@ struct SceneModule {
 // Returns false and fills `log` on failure.
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
 
+// The compile step alone (no device needed): true if `source` compiles for gfx950.
+bool check_scene_source(const std::string &source, std::string &log);
+
 hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
                                WorkCounters *counters, hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,

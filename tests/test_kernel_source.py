@@ -1,0 +1,27 @@
+"""The compiled kernel mode's host half, without a GPU: source generation for every shipped scene and a gfx950
+compile of it with hiprtc (what rm_set_scene does before it loads the code object)."""
+import os
+
+import pytest
+
+from conftest import scene_path
+
+
+@pytest.mark.parametrize("name,lattice", [("default.txt", True), ("default.txt", False), ("menger2.txt", True),
+                                          ("closeup6.txt", True), ("synthetic1024.txt", True)])
+def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
+    src = rm.kernel_source(rm.Scene(scene_path(name)), lattice=lattice)
+    assert 'extern "C" __global__' in src and "rm_trace" in src and "rm_eval_sdf" in src
+    assert ("lattice_sd<" in src) == (lattice and name != "synthetic1024.txt")
+    assert ("fold_run_clustered<" in src) == (name == "synthetic1024.txt")
+    rm.kernel_source_compiles(src)
+
+
+def test_counting_variant_and_compile_errors(rm):
+    scene = rm.Scene(scene_path("menger2.txt"))
+    counted = rm.kernel_source(scene, counting=True)
+    assert "trace_body<CompiledScene, 1, true>" in counted
+    rm.kernel_source_compiles(counted)
+    with pytest.raises(rm.RaymarchError) as e:
+        rm.kernel_source_compiles(counted.replace("single_sd<", "no_such_function<", 1))
+    assert "no_such_function" in str(e.value)
