@@ -218,45 +218,87 @@ __device__ __forceinline__ bool hull_needs_rows(const RowWords ra, const RowWord
     return !(v - eps >= need);
 }
 
-template <uint32_t KIND, bool NEG, bool MAX, int NP, bool COUNT>
-__device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count, uint32_t cfirst,
-                                                   uint32_t sfirst, float magnitude, const V3 (&p)[NP], float (&acc)[NP],
-                                                   Work (&work)[NP]) {
-    static_assert(NEG == MAX, "hulls give lower bounds: only folds that keep small distances can use them");
-    float eps[NP];
+// Crosses are three infinite bars (along z: max(dx, dy); along y: max(dx, dz); along x: max(dy, dz);
+// the cross distance, the median of the three axis terms, is the smallest of the three), so a hull
+// in space bounds them poorly.  A run of crosses is listed three times instead, once per bar
+// direction, each listing sorted and grouped by the two coordinates that place that bar, with flat
+// hulls (ra = centre a, centre b, half a, half b) that bound the bar's distance from below.  A cross
+// that could still win is close to p with at least one of its bars, hence inside a group that the
+// listing of that bar direction does not rule out, and is evaluated there with the plain formula;
+// evaluating it from two listings is harmless (min and max are idempotent).
+template <int DIR, bool NEG>
+__device__ __forceinline__ bool bar_hull_needs_rows(const RowWords ra, V3 p, float acc, float eps) {
+    const float need = NEG ? -acc : acc;
+    const float pa_ = DIR == 2 ? p.y : p.x, pb_ = DIR == 0 ? p.y : p.z;   // DIR 0: (x, y), 1: (x, z), 2: (y, z)
+    const float da = __builtin_fabsf(pa_ - ra[0]) - ra[2];
+    const float db = __builtin_fabsf(pb_ - ra[1]) - ra[3];
+    return !(__builtin_fmaxf(da, db) - eps >= need);
+}
+
+// One listing: rows [base, base + count), then a hull per 8 rows, then (long runs) a hull per 8 hulls.
+// DIR < 0: hulls of the run's own kind; DIR = 0..2: flat bar hulls.
+template <uint32_t KIND, int DIR, bool NEG, bool MAX, int NP>
+__device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_t base, uint32_t count, bool has_supers,
+                                             const V3 (&p)[NP], float (&acc)[NP], const float (&eps)[NP], uint32_t &tested,
+                                             uint32_t &evaluated) {
     uint32_t no_prim[NP];
 #pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        eps[n] = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + magnitude);
-        no_prim[n] = kNoPrim;
-    }
+    for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;
     const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
-    const uint32_t n_supers = sfirst != kNoRow ? (n_clusters + kClusterSize - 1u) / kClusterSize : 1u;
-    uint32_t tested = 0, evaluated = 0;
+    const uint32_t n_supers = has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 1u;
+    const uint32_t cfirst = base + count, sfirst = cfirst + n_clusters;
     for (uint32_t s = 0; s < n_supers; ++s) {
         uint32_t c0 = 0, c1 = n_clusters;
-        if (sfirst != kNoRow) {
-            const RowWords ha = pa[sfirst + s], hb = pb[sfirst + s];
+        if (has_supers) {
+            const RowWords ha = pa[sfirst + s];
+            RowWords hb = ha;
+            if (DIR < 0) hb = pb[sfirst + s];
             bool need = false;
 #pragma unroll
-            for (int n = 0; n < NP; ++n) need = need || hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n]);
+            for (int n = 0; n < NP; ++n)
+                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n])
+                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], acc[n], eps[n]));
             tested++;
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
             c0 = s * kClusterSize;
             c1 = c0 + kClusterSize < n_clusters ? c0 + kClusterSize : n_clusters;
         }
         for (uint32_t c = c0; c < c1; ++c) {
-            const RowWords ha = pa[cfirst + c], hb = pb[cfirst + c];
+            const RowWords ha = pa[cfirst + c];
+            RowWords hb = ha;
+            if (DIR < 0) hb = pb[cfirst + c];
             bool need = false;
 #pragma unroll
-            for (int n = 0; n < NP; ++n) need = need || hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n]);
+            for (int n = 0; n < NP; ++n)
+                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n])
+                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], acc[n], eps[n]));
             tested++;
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
             const uint32_t i0 = c * kClusterSize;
             const uint32_t rows = i0 + kClusterSize < count ? kClusterSize : count - i0;
-            fold_run<KIND, NEG, MAX, NP, false>(pa, pb, (ConstIndex)0, first + i0, rows, p, acc, no_prim);
+            fold_run<KIND, NEG, MAX, NP, false>(pa, pb, (ConstIndex)0, base + i0, rows, p, acc, no_prim);
             evaluated += rows;
         }
+    }
+}
+
+template <uint32_t KIND, bool NEG, bool MAX, int NP, bool COUNT>
+__device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count, bool has_supers,
+                                                   float magnitude, const V3 (&p)[NP], float (&acc)[NP], Work (&work)[NP]) {
+    static_assert(NEG == MAX, "hulls give lower bounds: only folds that keep small distances can use them");
+    float eps[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        eps[n] = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + magnitude);
+    uint32_t tested = 0, evaluated = 0;
+    if (KIND == K_CROSS || KIND == K_CROSS_ISO) {
+        const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
+        const uint32_t stride = count + n_clusters + (has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 0u);
+        fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, eps, tested, evaluated);
+        fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, has_supers, p, acc, eps, tested, evaluated);
+        fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, has_supers, p, acc, eps, tested, evaluated);
+    } else {
+        fold_listing<KIND, -1, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, eps, tested, evaluated);
     }
     if (COUNT) {
 #pragma unroll
@@ -272,9 +314,9 @@ template <uint32_t KIND, int NP, bool COUNT>
 __device__ __forceinline__ void fold_run_clustered_kind(const SceneView &sc, const RecWords &r, const V3 (&p)[NP],
                                                         float (&acc)[NP], Work (&work)[NP]) {
     if (r[6] & FOLD_MAX)
-        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3], r[4], __uint_as_float(r[5]), p, acc, work);
+        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, work);
     else
-        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3], r[4], __uint_as_float(r[5]), p, acc, work);
+        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, work);
 }
 
 // ---- LATTICE: a complete Menger lattice of cubic crosses, folded with max(s, -cross) ----------

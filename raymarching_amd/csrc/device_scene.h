@@ -53,13 +53,13 @@ constexpr uint32_t kNoRow = 0xffffffffu;
 //              gathered in depth-first order (a fold may run in any order: ties between equal
 //              distances are broken by depth-first index, which keeps the earlier child)
 //              With RUN_CLUSTERED (folds that keep small values of v: min(s, c) and max(s, -c)):
-//              h = (first cluster hull row, first super-cluster hull row or kNoRow, magnitude bound
-//              as float bits).  The run's rows are sorted along a space-filling curve; every 8
-//              consecutive rows have a hull row -- a primitive of the same kind (sphere, box or
-//              cross with three half sizes) that contains them, so that its distance is a lower
-//              bound of theirs -- and every 8 consecutive hulls a hull of their own.  Hull rows sit
-//              in the same tables, outside every run.  A hull whose distance cannot beat the
-//              accumulator rules out all rows below it.
+//              h = (1 if there are hulls of hulls, unused, magnitude bound as float bits).  The
+//              run's rows are sorted along a space-filling curve and followed, in the tables, by
+//              a hull row per 8 consecutive rows -- a primitive of the same kind (sphere, box)
+//              that contains them, so that its distance is a lower bound of theirs -- and, for
+//              runs of 128 rows or more, a hull per 8 hulls.  A hull whose distance cannot beat
+//              the accumulator rules out all rows below it.  Runs of crosses hold three such
+//              listings back to back, one per bar direction (device_core.h: bar_hull_needs_rows).
 //   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
 //   PUSH:      a[0] = slot, a[1] = identity of the list that starts (float bits)
 //   POP:       a[0] = slot

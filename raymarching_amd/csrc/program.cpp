@@ -310,43 +310,42 @@ struct Compiler {
         h[2] = one ? r.a.w : r.b.y;
     }
 
-    // Hull of rows[i0, i1): a primitive of the run's kind (three half sizes) that contains them all,
-    // padded by 1e-6 relative so that the rounding of its own centre and sizes cannot let a row stick out.
-    static Row hull_of(uint32_t kind, const std::vector<Row> &rows, size_t i0, size_t i1, const std::vector<Row> *members = nullptr,
-                       size_t m0 = 0, size_t m1 = 0) {
-        // `members`: the primitives below (for hulls of hulls, the rows the child hulls stand for)
-        const std::vector<Row> &prim = members ? *members : rows;
-        const size_t p0 = members ? m0 : i0, p1 = members ? m1 : i1;
+    // Hull of rows[i0, i1), padded by 1e-6 relative so that the rounding of its own centre and sizes
+    // cannot let a row stick out.  dir < 0: a primitive of the run's kind (sphere; box or cross with
+    // three half sizes) that contains the rows.  dir = 0, 1, 2: the flat hull of the rows' bars along
+    // z, y, x -- a = (centre a, centre b, half a, half b) on the two axes that place the bar.
+    static Row hull_of(uint32_t kind, int dir, const std::vector<Row> &rows, size_t i0, size_t i1) {
         double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (size_t i = p0; i < p1; i++) {
+        for (size_t i = i0; i < i1; i++) {
             double h[3];
-            extents(kind, prim[i], h);
-            const double c[3] = { prim[i].a.x, prim[i].a.y, prim[i].a.z };
+            extents(kind, rows[i], h);
+            const double c[3] = { rows[i].a.x, rows[i].a.y, rows[i].a.z };
             for (int k = 0; k < 3; k++) {
                 lo[k] = std::fmin(lo[k], c[k] - h[k]);
                 hi[k] = std::fmax(hi[k], c[k] + h[k]);
             }
         }
+        float cf[3], hf[3];
+        for (int k = 0; k < 3; k++) {
+            cf[k] = (float)((lo[k] + hi[k]) / 2);
+            const double h = std::fmax(hi[k] - (double)cf[k], (double)cf[k] - lo[k]);
+            hf[k] = round_up(h * (1.0 + 1e-6) + 1e-6 * std::fabs((double)cf[k]) + 1e-30);
+        }
         Row out{};
-        const float cf[3] = { (float)((lo[0] + hi[0]) / 2), (float)((lo[1] + hi[1]) / 2), (float)((lo[2] + hi[2]) / 2) };
-        out.a = Float4{ cf[0], cf[1], cf[2], 0.0f };
-        if (kind == K_SPHERE) {
+        if (dir >= 0) {
+            const int ka = dir == 2 ? 1 : 0, kb = dir == 0 ? 1 : 2;
+            out.a = Float4{ cf[ka], cf[kb], hf[ka], hf[kb] };
+        } else if (kind == K_SPHERE) {
             double radius = 0.0;
-            for (size_t i = p0; i < p1; i++) {
-                const double dx = (double)prim[i].a.x - cf[0], dy = (double)prim[i].a.y - cf[1], dz = (double)prim[i].a.z - cf[2];
-                radius = std::fmax(radius, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)prim[i].a.w);
+            for (size_t i = i0; i < i1; i++) {
+                const double dx = (double)rows[i].a.x - cf[0], dy = (double)rows[i].a.y - cf[1], dz = (double)rows[i].a.z - cf[2];
+                radius = std::fmax(radius, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)rows[i].a.w);
             }
-            out.a.w = round_up(radius * (1.0 + 1e-6) + 1e-30);
+            out.a = Float4{ cf[0], cf[1], cf[2], round_up(radius * (1.0 + 1e-6) + 1e-30) };
         } else {
-            float hf[3];
-            for (int k = 0; k < 3; k++) {
-                const double h = std::fmax(hi[k] - (double)cf[k], (double)cf[k] - lo[k]);
-                hf[k] = round_up(h * (1.0 + 1e-6) + 1e-6 * std::fabs((double)cf[k]) + 1e-30);
-            }
-            out.a.w = hf[0];
+            out.a = Float4{ cf[0], cf[1], cf[2], hf[0] };
             out.b = Float4{ hf[1], hf[2], 0.0f, 0.0f };
         }
-        (void)i0; (void)i1;
         return out;
     }
 
@@ -356,6 +355,39 @@ struct Compiler {
         out.row_prim.push_back(r.prim);
     }
 
+    // One listing of a clustered run: the rows sorted along a Morton curve (over all three centre
+    // coordinates, or over the two that place the bars of direction `dir`), a hull per 8 rows, and
+    // for long runs a hull per 64.
+    void emit_listing(uint32_t kind, int dir, std::vector<Row> rows, bool supers) {
+        double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (const Row &row : rows) {
+            const double c[3] = { row.a.x, row.a.y, row.a.z };
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::fmin(lo[k], c[k]);
+                hi[k] = std::fmax(hi[k], c[k]);
+            }
+        }
+        const int skip = dir == 0 ? 2 : (dir == 1 ? 1 : (dir == 2 ? 0 : -1));   // the axis the bars run along
+        for (Row &row : rows) {
+            const double c[3] = { row.a.x, row.a.y, row.a.z };
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                const double span = hi[k] - lo[k];
+                q[k] = (span > 0.0 && k != skip) ? (uint32_t)std::fmin(2097151.0, (c[k] - lo[k]) / span * 2097151.0) : 0u;
+            }
+            row.key = spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2;
+        }
+        std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.key < y.key; });
+        for (const Row &row : rows) push_row(row);
+        const size_t n_clusters = (rows.size() + kClusterSize - 1) / kClusterSize;
+        for (size_t c = 0; c < n_clusters; c++)
+            push_row(hull_of(kind, dir, rows, c * kClusterSize, std::min(rows.size(), (c + 1) * kClusterSize)));
+        if (supers) {
+            const size_t per = (size_t)kClusterSize * kClusterSize, n_supers = (n_clusters + kClusterSize - 1) / kClusterSize;
+            for (size_t s = 0; s < n_supers; s++) push_row(hull_of(kind, dir, rows, s * per, std::min(rows.size(), (s + 1) * per)));
+        }
+    }
+
     void emit_run(uint32_t kind, const Bucket &bk, uint32_t fold) {
         std::vector<Row> rows(bk.node.size());
         for (size_t i = 0; i < rows.size(); i++) {
@@ -363,7 +395,7 @@ struct Compiler {
             rows[i].prim = bk.prim[i];
         }
         Rec r = {};
-        r.a[1] = (uint32_t)rows.size(); r.a[2] = kind;
+        r.a[0] = (uint32_t)out.pa.size(); r.a[1] = (uint32_t)rows.size(); r.a[2] = kind;
         r.flags = REC_RUN | fold;
         out.run_prims += (uint32_t)rows.size();
         // hulls bound distances from below: of use to the folds that keep small distances
@@ -380,45 +412,18 @@ struct Compiler {
             }
         }
         if (use_lattice && keeps_small && finite && rows.size() >= 2 * kClusterSize) {
-            // sort along a Morton curve over the centres' bounding box
-            double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-            for (const Row &row : rows) {
-                const double c[3] = { row.a.x, row.a.y, row.a.z };
-                for (int k = 0; k < 3; k++) {
-                    lo[k] = std::fmin(lo[k], c[k]);
-                    hi[k] = std::fmax(hi[k], c[k]);
-                }
+            const bool supers = rows.size() >= 2 * kClusterSize * kClusterSize;
+            if (kind == K_CROSS || kind == K_CROSS_ISO) {
+                for (int dir = 0; dir < 3; dir++) emit_listing(kind, dir, rows, supers);
+            } else {
+                emit_listing(kind, -1, rows, supers);
             }
-            for (Row &row : rows) {
-                const double c[3] = { row.a.x, row.a.y, row.a.z };
-                uint32_t q[3];
-                for (int k = 0; k < 3; k++) {
-                    const double span = hi[k] - lo[k];
-                    q[k] = span > 0.0 ? (uint32_t)std::fmin(2097151.0, (c[k] - lo[k]) / span * 2097151.0) : 0u;
-                }
-                row.key = spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2;
-            }
-            std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.key < y.key; });
-            const size_t n_clusters = (rows.size() + kClusterSize - 1) / kClusterSize;
-            std::vector<Row> clusters(n_clusters);
-            for (size_t c = 0; c < n_clusters; c++)
-                clusters[c] = hull_of(kind, rows, c * kClusterSize, std::min(rows.size(), (c + 1) * kClusterSize));
-            r.h[0] = (uint32_t)out.pa.size();
-            for (const Row &c : clusters) push_row(c);
-            r.h[1] = kNoRow;
-            if (n_clusters >= 2 * kClusterSize) {
-                r.h[1] = (uint32_t)out.pa.size();
-                const size_t n_supers = (n_clusters + kClusterSize - 1) / kClusterSize;
-                for (size_t s = 0; s < n_supers; s++) {
-                    const size_t m0 = s * kClusterSize * kClusterSize, m1 = std::min(rows.size(), (s + 1) * kClusterSize * kClusterSize);
-                    push_row(hull_of(kind, clusters, 0, 0, &rows, m0, m1));
-                }
-            }
+            r.h[0] = supers ? 1u : 0u;
             r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
             r.flags |= RUN_CLUSTERED;
+        } else {
+            for (const Row &row : rows) push_row(row);
         }
-        r.a[0] = (uint32_t)out.pa.size();
-        for (const Row &row : rows) push_row(row);
         out.recs.push_back(r);
     }
 
