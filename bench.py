@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--emulate-share", type=int, default=0,
                     help="diagnostic, 1 GPU only: render rank 0's share of an N-way split (no gather); value is "
                          "this one GPU's rate times N, an upper bound for the N-GPU run")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank run with every rank on cuda:0 and the gloo backend: exercises the N > 1 code path "
+                         "(sharding, asynchronous gather, assembly) where only one GPU is at hand; its numbers mean nothing")
     ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive-leg", action="store_true")
@@ -128,9 +131,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and a.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if a.rehearse_on_one_gpu:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)   # a rehearsal that hangs says where
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     scene_name, kw, desc = WORKLOADS[a.workload]
     scene_file = os.path.join(ROOT, "scenes", scene_name)
@@ -165,7 +175,7 @@ def main():
         rows, local_rows = sharding.band_plan(H, a.band_rows, a.emulate_share, 0)
     shards = [torch.empty((local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F)]
     shard = shards[0]
-    gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank) for f in range(F)]
+    gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu) for f in range(F)]
     streams = [torch.cuda.Stream() for _ in range(F)]
     works = [None] * F
 
@@ -219,6 +229,15 @@ def main():
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
     for rr in rs:
         rr.set_stream(None)
+
+    # ---- self-check of the sharded path (outside the timed region): the frames gathered on rank 0 must equal
+    # the frame one launch renders
+    gathered_ok = None
+    if world > 1 and rank == 0:
+        whole, _ = sharding.band_plan(H, a.band_rows, 1, 0)
+        single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        r.render_device(whole, None, single.data_ptr())
+        gathered_ok = all(bool(torch.equal(g.frame(), single)) for g in gatherers[:min(F, a.steps + a.warmup)])
 
     stats = torch.tensor([elapsed, kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])],
                          dtype=torch.float64, device="cuda")
@@ -286,6 +305,7 @@ def main():
                                            "tflops": round(local_algo / (kernel_ms * 1e-3) / 1e12, 2)},
                 "note": "peak is the FMA-every-slot datasheet figure; this path has no multiply-adds to fuse, its instruction mix tops out near 80 TFLOP/s (tools/valu_bench.hip)",
             },
+            "gathered_frame_equals_single_launch": gathered_ok,
             "frame_ms": round(ms_per_step, 4),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }

@@ -56,10 +56,13 @@ class FrameGatherer:
     once the stream has reached the copy.
     """
 
-    def __init__(self, shard, height, band_rows, world, rank):
+    def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False):
+        """stage_on_host: gather through host copies, blocking, for backends without device collectives
+        (gloo with GPU shards: rehearsals and tests only)."""
         import torch
 
         self.height, self.band_rows, self.world, self.rank = height, band_rows, world, rank
+        self.stage_on_host = stage_on_host
         self.stack = self.out = None
         if world > 1 and rank == 0:
             self.stack = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
@@ -73,9 +76,19 @@ class FrameGatherer:
         if self.world == 1:
             self.single = shard
             return None
-        work = dist.gather(shard, self.parts if self.rank == 0 else None, dst=0, async_op=True)
+        if self.stage_on_host:
+            import torch
+            host = shard.cpu()   # waits for the current stream
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            work = None
+            if self.rank == 0:
+                self.stack.copy_(torch.stack(parts))
+        else:
+            work = dist.gather(shard, self.parts if self.rank == 0 else None, dst=0, async_op=True)
         if self.rank == 0:
-            work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
+            if work is not None:
+                work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
             local_rows, width, ch = self.stack.shape[1:]
             nb = local_rows // self.band_rows
             src = self.stack.view(self.world, nb, self.band_rows, width, ch).permute(1, 0, 2, 3, 4)
