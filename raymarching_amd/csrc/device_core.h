@@ -117,11 +117,28 @@ __device__ __forceinline__ bool value_can_change(float acc, float v) {
 // body into unconditional code with selects).
 __device__ __forceinline__ void keep_in_branch() { asm volatile(""); }
 
+// For the folds that a sphere can change only when S = |c - p| is small (see sphere_cannot_change):
+// true if the largest coordinate difference m alone proves S >= T.  S is computed from the same
+// differences, so S >= m (1 - 2^-22) whatever the roundings of the squares, sums and root; with
+// T' = (acc + r or r - acc) rounded, m >= T' (1 + 1e-6) gives S >= T.  T' <= 0 passes as it must
+// (the sphere's value is at least -r); NaNs fail.  Seven instructions against the thirteen of the
+// squared test, and enough for most spheres that are far from p.
+template <bool NEG>
+__device__ __forceinline__ bool sphere_far(float acc, float dx, float dy, float dz, float r) {
+    const float t = NEG ? r - acc : acc + r;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)), __builtin_fabsf(dz));
+    return m >= t * 1.000001f;
+}
+
 template <bool NEG, bool MAX>
 __device__ __forceinline__ float fold_sphere(float acc, V3 p, float cx, float cy, float cz, float r) {
-    // One wave-uniform branch: taken, every lane folds (the fold is exact for all of them).  The
+    // Wave-uniform branches: taken, every lane folds (the fold is exact for all of them).  The
     // empty asm keeps the compiler from hoisting the square root out of the branch.
-    float d2 = sphere_d2(p, cx, cy, cz);
+    const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+    if (NEG == MAX) {
+        if (__builtin_amdgcn_ballot_w64(!sphere_far<NEG>(acc, dx, dy, dz, r)) == 0) return acc;
+    }
+    float d2 = dx * dx + dy * dy + dz * dz;
     if (__builtin_amdgcn_ballot_w64(!sphere_cannot_change<NEG, MAX>(acc, d2, r)) != 0) {
         asm volatile("" : "+v"(d2));
         acc = fold_sd<NEG, MAX>(acc, __builtin_sqrtf(d2) - r);
