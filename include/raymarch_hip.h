@@ -197,7 +197,7 @@ typedef enum rm_kernel_mode { RM_KERNEL_INTERPRETED = 0, RM_KERNEL_COMPILED = 1 
 int rm_set_kernel_mode(rm_context *ctx, int mode);
 
 /*
- * Order in which the trace kernel's 16x16-sample tiles are started (no counterpart in the
+ * Order in which the trace kernel's tiles (one workgroup each: 8x8 or 16x16 samples) are started (no counterpart in the
  * reference; the frame is the same either way).
  *   RM_TILES_BY_COST  (default) the first render of a configuration -- scene upload, parameters,
  *                     row bands -- times every tile; later renders of the same configuration

@@ -152,7 +152,8 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     // ---- tile schedule of this launch
     const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
-    pend.n_tiles = (size_t)((sw + 16u * pts - 1u) / (16u * pts)) * ((sh + 15u) / 16u);
+    const uint32_t side = (compiled && ctx->module.waves_per_group == 1u) ? 8u : 16u;
+    pend.n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
     if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
         rm_context::OrderKey key{};
         key.params = ctx->params;
@@ -180,8 +181,8 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     }
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
-                                         ctx->counting_module, log))
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, (int)ctx->module.waves_per_group, true),
+                                         kCompiledPts, ctx->module.waves_per_group, ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -345,8 +346,11 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     ctx->module.unload();
     ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
+        // One wave per workgroup schedules finest (a workgroup lasts as long as its slowest wave), but every
+        // workgroup stages the lattice tables into LDS: large tables are shared by four waves instead.
+        const int group = ctx->program.lattice.size() > 1024 ? 4 : 1;
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false), kCompiledPts, ctx->module, log)) {
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, group, false), kCompiledPts, (uint32_t)group, ctx->module, log)) {
             ctx->have_scene = false;
             return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
         }
@@ -443,7 +447,7 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
     std::string why;
     rmdev::HostProgram prog;
     if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_kernel_source: " + why);
-    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, counting != 0);
+    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, prog.lattice.size() > 1024 ? 4 : 1, counting != 0);
     *length = src.size();
     if (buffer && capacity) {
         const size_t n = src.size() < capacity - 1 ? src.size() : capacity - 1;

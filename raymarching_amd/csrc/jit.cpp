@@ -65,7 +65,8 @@ void SceneModule::unload() {
 
 bool check_scene_source(const std::string &source, std::string &log) { return build_code_object(source, log) != nullptr; }
 
-bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
+                          std::string &log) {
     out.unload();
     CodeObject code;
     {
@@ -98,6 +99,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         }
     }
     out.points_per_lane = points_per_lane;
+    out.waves_per_group = waves_per_group;
     out.compile_seconds = seconds;
     return true;
 }
@@ -117,7 +119,8 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
     SceneView sc_arg = sc;
     FrameView fr_arg = fr;
     void *args[] = { &sc_arg, &fr_arg, &samples, &counters };
-    return hipModuleLaunchKernel(m.trace, (sw + 16u * pts - 1u) / (16u * pts), (sh + 15u) / 16u, 1, 256, 1, 1,
+    const uint32_t side = m.waves_per_group == 4u ? 16u : 8u;
+    return hipModuleLaunchKernel(m.trace, (sw + side * pts - 1u) / (side * pts), (sh + side - 1u) / side, 1, 64u * m.waves_per_group, 1, 1,
                                  lds_bytes_of(sc), stream, args, nullptr);
 }
 

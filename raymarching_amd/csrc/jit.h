@@ -22,6 +22,7 @@ struct SceneModule {
     hipFunction_t trace = nullptr;
     hipFunction_t eval_sdf = nullptr;
     uint32_t points_per_lane = 0;   // of `trace`
+    uint32_t waves_per_group = 4;   // of `trace`: 4 (16 x 16 lanes) or 1 (8 x 8)
     double compile_seconds = 0.0;   // 0 when the code came from the process-wide cache
     bool loaded() const { return module != nullptr; }
     void unload();
@@ -30,7 +31,8 @@ struct SceneModule {
 // Compiles `source` (see codegen.cpp) for gfx950 and loads it on the current device.  Code objects
 // are cached per process by source text, so uploading the same scene again costs no compile.
 // Returns false and fills `log` on failure.
-bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
+                          std::string &log);
 
 // The compile step alone (no device needed): true if `source` compiles for gfx950.
 bool check_scene_source(const std::string &source, std::string &log);

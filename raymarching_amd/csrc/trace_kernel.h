@@ -52,7 +52,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 // kPts = 1: block = 16 x 16, wave = 8 x 8, one sample per lane -- for scenes whose cost is in long
 // primitive runs (vector-ALU bound), where idling would cost more than the scalar unit saves.
 // MIN_WAVES: waves per SIMD the register allocation must allow.
-template <class Scene, int kPts, bool COUNT>
+template <class Scene, int kPts, bool COUNT, int kWaves = 4>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Float4 *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
     __shared__ unsigned long long block_counts[6];
@@ -68,8 +68,10 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t tile = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
     const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
-    const uint32_t sx0 = tile_x * (16u * kPts) + (wave & 1u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
-    const uint32_t sy = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    // kWaves = 4: a workgroup is 2 x 2 waves of 8 x 8 lanes; kWaves = 1: one wave
+    constexpr uint32_t kSide = kWaves == 4 ? 2u : 1u;
+    const uint32_t sx0 = tile_x * (8u * kSide * kPts) + (kWaves == 4 ? (wave & 1u) : 0u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
+    const uint32_t sy = tile_y * (8u * kSide) + (kWaves == 4 ? (wave >> 1) : 0u) * 8u + (lane >> 3);
     LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
