@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd|closeup6|synthetic]
                     [--evaluator lattice|exhaustive] [--kernel-mode compiled|interpreted]
 
-A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4),
+A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4; 8 from eight GPUs on),
 each on its own stream, alternate frames: the timed region holds exactly K whole frames, all finished
 (streams drained) before the clock stops.  At N > 1 (one process per GPU, launched by
 torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
@@ -38,6 +38,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Frames in flight run on one HIP stream each; HIP maps streams onto this many hardware queues per process
+# (its default, 4, would let only four frames overlap).  Read when the runtime starts, hence set before torch.
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import torch  # noqa: E402  (first: the renderer must share torch's HIP runtime)
 import torch.distributed as dist  # noqa: E402
 
@@ -63,7 +68,9 @@ def parse():
     ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS))
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
-    ap.add_argument("--frames-in-flight", type=int, default=4, help="contexts/streams per GPU that alternate frames")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="contexts/streams per GPU that alternate frames (default: 4, and 8 on eight GPUs or more, where one "
+                         "rank's share of a frame is short against its longest-running tiles)")
     ap.add_argument("--emulate-share", type=int, default=0,
                     help="diagnostic, 1 GPU only: render rank 0's share of an N-way split (no gather); value is "
                          "this one GPU's rate times N, an upper bound for the N-GPU run")
@@ -150,7 +157,7 @@ def main():
     # ---- contexts: one per frame in flight, each on its own stream (frames are independent; the tail of one
     # frame's long-running tiles overlaps the start of the next frame, and the gather of frame i overlaps the
     # render of frame i + 1)
-    F = max(1, a.frames_in_flight)
+    F = a.frames_in_flight if a.frames_in_flight > 0 else (8 if max(world, a.emulate_share) >= 8 else 4)
     rs, set_scene_s = [], 0.0
     for f in range(F):
         rr = rm.Renderer(local)
@@ -176,7 +183,9 @@ def main():
     shards = [torch.empty((local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F)]
     shard = shards[0]
     gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu) for f in range(F)]
-    streams = [torch.cuda.Stream() for _ in range(F)]
+    # every context's own HIP stream, seen from PyTorch (streams the library creates land on distinct hardware
+    # queues in creation order; streams of PyTorch's pool do not)
+    streams = [torch.cuda.ExternalStream(rr.stream) for rr in rs]
     works = [None] * F
 
     # ---- work count of this rank's share (counting kernel variant, outside the timed region)
@@ -196,8 +205,6 @@ def main():
             if i >= 2:
                 iso.append(rr.counters()["kernel_ms"])
     kernel_ms = sum(iso) / len(iso)
-    for rr, st in zip(rs, streams):
-        rr.set_stream(st.cuda_stream)
 
     def frame(i):
         f = i % F
@@ -227,9 +234,6 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
-    for rr in rs:
-        rr.set_stream(None)
-
     # ---- self-check of the sharded path (outside the timed region): the frames gathered on rank 0 must equal
     # the frame one launch renders
     gathered_ok = None

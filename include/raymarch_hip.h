@@ -208,6 +208,9 @@ int rm_set_kernel_mode(rm_context *ctx, int mode);
  */
 typedef enum rm_tile_scheduling { RM_TILES_NATURAL = 0, RM_TILES_BY_COST = 1 } rm_tile_scheduling;
 int rm_set_tile_scheduling(rm_context *ctx, int mode);
+/* The durations the last tile-timing render measured, in 10 ns ticks, row-major over the tile grid
+ * of that render's sample image (tiles_x * tiles_y entries; ticks may be NULL to ask for the shape). */
+int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /*
  * The compiled mode's two steps without a device or a context (build checks, inspection):

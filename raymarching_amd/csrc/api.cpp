@@ -97,6 +97,7 @@ struct rm_context {
     uint64_t scene_serial = 0;
     OrderKey order_key{};
     bool order_ready = false;
+    uint32_t measured_tiles_x = 0, measured_tiles_y = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
 
     // the frame enqueued last and not yet booked by finish_bands
@@ -167,6 +168,8 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->order_key = key;
             ctx->order_ready = false;
             pend.measuring = true;
+            ctx->measured_tiles_x = (sw + side * pts - 1u) / (side * pts);
+            ctx->measured_tiles_y = (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
             RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles));
             fr.tile_cost = ctx->d_tile_cost.ptr;
@@ -484,6 +487,20 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode) {
     if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
     ctx->tile_scheduling = mode;
     ctx->order_ready = false;
+    return RM_OK;
+}
+
+int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_t *tiles_x, uint32_t *tiles_y) {
+    if (!ctx || !tiles_x || !tiles_y) return fail(RM_ERR_INVALID, "rm_get_tile_costs: null argument");
+    if (!ctx->order_ready) return fail(RM_ERR_STATE, "rm_get_tile_costs: no render has timed its tiles yet");
+    *tiles_x = ctx->measured_tiles_x;
+    *tiles_y = ctx->measured_tiles_y;
+    const size_t n = (size_t)ctx->measured_tiles_x * ctx->measured_tiles_y;
+    if (ticks) {
+        if (capacity < n) return fail(RM_ERR_INVALID, "rm_get_tile_costs: capacity too small");
+        RM_HIP(hipSetDevice(ctx->device));
+        RM_HIP(hipMemcpy(ticks, ctx->d_tile_cost.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     return RM_OK;
 }
 
