@@ -339,7 +339,11 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     RM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this call
     ctx->program = std::move(prog);
     rmdev::SceneView &sv = ctx->scene;
-    sv.recs = ctx->d_recs.ptr; sv.n_recs = static_cast<uint32_t>(ctx->program.recs.size()) - 1u; sv.max_depth = ctx->program.max_depth; sv.root_identity = ctx->program.root_identity; sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr; sv.row_prim = ctx->d_row_prim.ptr;
+    sv.recs = ctx->d_recs.ptr;
+    sv.n_recs = static_cast<uint32_t>(ctx->program.recs.size()) - 1u;
+    sv.max_depth = ctx->program.max_depth;
+    sv.root_identity = ctx->program.root_identity;
+    sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr; sv.row_prim = ctx->d_row_prim.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
     sv.lattice = ctx->d_lattice.ptr;
@@ -353,7 +357,8 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         // workgroup stages the lattice tables into LDS: large tables are shared by four waves instead.
         const int group = ctx->program.lattice.size() > 1024 ? 4 : 1;
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, group, false), kCompiledPts, (uint32_t)group, ctx->module, log)) {
+        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, group, false);
+        if (!rmdev::compile_scene_module(source, kCompiledPts, (uint32_t)group, ctx->module, log)) {
             ctx->have_scene = false;
             return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
         }

@@ -279,9 +279,10 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
     char buf[512];
     std::snprintf(buf, sizeof buf,
-                  "extern \"C\" __global__ __launch_bounds__(%d, %d) void rm_trace(const SceneView sc, const FrameView fr, Float4 *samples,\n"
+                  "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(const SceneView sc, const FrameView fr, Float4 *samples,\n"
                   "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s, %d>(sc, fr, samples, counters);\n}\n\n",
-                  64 * waves_per_group, min_waves, points_per_lane, counting ? "true" : "false", waves_per_group);
+                  64 * waves_per_group, min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane,
+                  counting ? "true" : "false", waves_per_group);
     s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
          "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n";

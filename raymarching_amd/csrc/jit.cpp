@@ -89,7 +89,10 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, u
         out.module = nullptr;
         return false;
     }
-    const struct { hipFunction_t *fn; const char *name; } symbols[] = { { &out.trace, "rm_trace" }, { &out.eval_sdf, "rm_eval_sdf" } };
+    // a module holds the plain kernel or its work-counting variant (named apart, so that profiles tell them apart)
+    const bool counting = source.find("rm_trace_counting") != std::string::npos;
+    const struct { hipFunction_t *fn; const char *name; } symbols[] = { { &out.trace, counting ? "rm_trace_counting" : "rm_trace" },
+                                                                         { &out.eval_sdf, "rm_eval_sdf" } };
     for (const auto &sym : symbols) {
         e = hipModuleGetFunction(sym.fn, out.module, sym.name);
         if (e != hipSuccess) {

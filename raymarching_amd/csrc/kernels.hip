@@ -1,22 +1,23 @@
-// kernels.hip -- gfx950 kernels of the sphere-tracing render path.
+// kernels.hip -- the ahead-of-time gfx950 kernels of the sphere-tracing render path: the trace
+// kernel that walks the scene's record stream (interp_scene.h), the SDF test hook and the resolve
+// kernel.  Kernels specialised for one scene are generated and compiled at upload time instead
+// (codegen.cpp, jit.cpp); both share the kernel body (trace_kernel.h).
 //
-// Two SSAA samples per lane (two horizontally adjacent sub-samples), 16 x 8 samples per
-// wave.  A lane does for each of its samples what scene::raymarch does
+// A lane does for each of its SSAA samples what scene::raymarch does
 // (/root/reference/source/scene.cpp:26-62): primary march, colour of the hit,
-// central-difference normal, one shadow march per light, clamped Lambert sum.  A second
+// central-difference normal, one shadow march per light, clamped Lambert sum.  The resolve
 // kernel averages each pixel's kernel x kernel samples in the reference's accumulation
 // order (render.cpp:103-119) and quantises.
 //
-// Arithmetic contract: every fp32 operation below is a single correctly rounded IEEE
-// operation in the reference's order -- compiled with -ffp-contract=off (no fused
-// multiply-add) and hipcc's default correctly rounded sqrt / divide -- so the float
-// framebuffer is bit-identical to the CPU path's (signs of zeros and NaN payloads aside).
+// Arithmetic contract: every fp32 operation that can reach the frame is a single correctly
+// rounded IEEE operation in the reference's order -- compiled with -ffp-contract=off (no fused
+// multiply-add) and hipcc's correctly rounded sqrt / divide -- so the float framebuffer is
+// bit-identical to the CPU path's (signs of zeros and NaN payloads aside).
 //
-// The scene is a flat record stream (device_scene.h).  All lanes of a wave walk the same
-// stream at the same time, so records and table rows are fetched through wave-uniform
-// addresses (scalar loads, operands in SGPRs); only the sample positions live in vector
-// registers.  The scalar unit, one per CU, pays for every record; evaluating two points
-// per lane per walk halves that cost per point.
+// The record walker: all lanes of a wave walk the same stream at the same time, so records and
+// table rows are fetched through wave-uniform addresses (scalar loads, operands in SGPRs); only
+// the sample positions live in vector registers.  The scalar unit, one per CU, pays for every
+// record; evaluating two points per lane per walk halves that cost per point.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
