@@ -358,7 +358,7 @@ struct Compiler {
     // One listing of a clustered run: the rows sorted along a Morton curve (over all three centre
     // coordinates, or over the two that place the bars of direction `dir`), a hull per 8 rows, and
     // for long runs a hull per 64.
-    void emit_listing(uint32_t kind, int dir, std::vector<Row> rows, bool supers) {
+    bool emit_listing(uint32_t kind, int dir, std::vector<Row> rows, bool supers) {
         double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (const Row &row : rows) {
             const double c[3] = { row.a.x, row.a.y, row.a.z };
@@ -380,12 +380,46 @@ struct Compiler {
         std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.key < y.key; });
         for (const Row &row : rows) push_row(row);
         const size_t n_clusters = (rows.size() + kClusterSize - 1) / kClusterSize;
-        for (size_t c = 0; c < n_clusters; c++)
-            push_row(hull_of(kind, dir, rows, c * kClusterSize, std::min(rows.size(), (c + 1) * kClusterSize)));
+        bool sound = true;
+        for (size_t c = 0; c < n_clusters; c++) {
+            const size_t i0 = c * kClusterSize, i1 = std::min(rows.size(), (c + 1) * kClusterSize);
+            const Row hull = hull_of(kind, dir, rows, i0, i1);
+            sound = sound && contains(kind, dir, hull, rows, i0, i1);
+            push_row(hull);
+        }
         if (supers) {
             const size_t per = (size_t)kClusterSize * kClusterSize, n_supers = (n_clusters + kClusterSize - 1) / kClusterSize;
-            for (size_t s = 0; s < n_supers; s++) push_row(hull_of(kind, dir, rows, s * per, std::min(rows.size(), (s + 1) * per)));
+            for (size_t s = 0; s < n_supers; s++) {
+                const size_t i0 = s * per, i1 = std::min(rows.size(), (s + 1) * per);
+                const Row hull = hull_of(kind, dir, rows, i0, i1);
+                sound = sound && contains(kind, dir, hull, rows, i0, i1);
+                push_row(hull);
+            }
         }
+        return sound;
+    }
+
+    // The invariant the kernels' pruning rests on, checked on the float values the device will read:
+    // every row's interval on every hull axis lies inside the hull's (spheres: inside the hull sphere).
+    static bool contains(uint32_t kind, int dir, const Row &hull, const std::vector<Row> &rows, size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            double h[3];
+            extents(kind, rows[i], h);
+            const double c[3] = { rows[i].a.x, rows[i].a.y, rows[i].a.z };
+            if (dir >= 0) {
+                const int ka = dir == 2 ? 1 : 0, kb = dir == 0 ? 1 : 2;
+                if (!(std::fabs(c[ka] - (double)hull.a.x) + h[ka] <= (double)hull.a.z)) return false;
+                if (!(std::fabs(c[kb] - (double)hull.a.y) + h[kb] <= (double)hull.a.w)) return false;
+            } else if (kind == K_SPHERE) {
+                const double dx = c[0] - (double)hull.a.x, dy = c[1] - (double)hull.a.y, dz = c[2] - (double)hull.a.z;
+                if (!(std::sqrt(dx * dx + dy * dy + dz * dz) + h[0] <= (double)hull.a.w)) return false;
+            } else {
+                const double hh[3] = { hull.a.w, hull.b.x, hull.b.y }, hc[3] = { hull.a.x, hull.a.y, hull.a.z };
+                for (int k = 0; k < 3; k++)
+                    if (!(std::fabs(c[k] - hc[k]) + h[k] <= hh[k])) return false;
+            }
+        }
+        return true;
     }
 
     void emit_run(uint32_t kind, const Bucket &bk, uint32_t fold) {
@@ -413,14 +447,23 @@ struct Compiler {
         }
         if (use_lattice && keeps_small && finite && rows.size() >= 2 * kClusterSize) {
             const bool supers = rows.size() >= 2 * kClusterSize * kClusterSize;
+            bool sound = true;
             if (kind == K_CROSS || kind == K_CROSS_ISO) {
-                for (int dir = 0; dir < 3; dir++) emit_listing(kind, dir, rows, supers);
+                for (int dir = 0; dir < 3; dir++) sound = emit_listing(kind, dir, rows, supers) && sound;
             } else {
-                emit_listing(kind, -1, rows, supers);
+                sound = emit_listing(kind, -1, rows, supers);
             }
-            r.h[0] = supers ? 1u : 0u;
-            r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
-            r.flags |= RUN_CLUSTERED;
+            if (sound) {
+                r.h[0] = supers ? 1u : 0u;
+                r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
+                r.flags |= RUN_CLUSTERED;
+            } else {
+                // never expected (the hulls are padded well beyond their rounding); a plain run is always right
+                out.pa.resize(r.a[0]);
+                out.pb.resize(r.a[0]);
+                out.row_prim.resize(r.a[0]);
+                for (const Row &row : rows) push_row(row);
+            }
         } else {
             for (const Row &row : rows) push_row(row);
         }
