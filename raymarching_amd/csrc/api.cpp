@@ -153,7 +153,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     // ---- tile schedule of this launch
     const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
-    const uint32_t side = (compiled && ctx->module.waves_per_group == 1u) ? 8u : 16u;
+    const uint32_t side = (compiled ? ctx->module.waves_per_group == 1u : wide_runs) ? 8u : 16u;   // see launch_trace
     pend.n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
     if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
         rm_context::OrderKey key{};

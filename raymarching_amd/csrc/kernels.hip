@@ -31,10 +31,12 @@ namespace {
 
 // kPts / MIN_WAVES variants: see trace_body.  MIN_WAVES = waves per SIMD the register
 // allocation must allow.
-template <int kPts, int MIN_WAVES, bool COUNT>
-__global__ __launch_bounds__(256, MIN_WAVES) void trace_kernel(const SceneView sc, const FrameView fr, Float4 *__restrict__ samples,
-                                                               WorkCounters *__restrict__ counters) {
-    trace_body<InterpretedScene, kPts, COUNT>(sc, fr, samples, counters);
+// kWaves: waves per workgroup (4: 16 x 16 lanes; 1: 8 x 8, finer scheduling for scenes whose tiles run long).
+template <int kPts, int MIN_WAVES, bool COUNT, int kWaves>
+__global__ __launch_bounds__(64 * kWaves, MIN_WAVES) void trace_kernel(const SceneView sc, const FrameView fr,
+                                                                       Float4 *__restrict__ samples,
+                                                                       WorkCounters *__restrict__ counters) {
+    trace_body<InterpretedScene, kPts, COUNT, kWaves>(sc, fr, samples, counters);
 }
 
 __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const float *__restrict__ xyz, uint32_t n,
@@ -90,15 +92,15 @@ hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0) return hipSuccess;
-    const uint32_t pts = wide_runs ? 1u : 2u;
-    const dim3 grid((sw + 16u * pts - 1u) / (16u * pts), (sh + 15u) / 16u, 1u);
     const uint32_t lds = lds_bytes(sc);
-    if (wide_runs) {
-        if (counters) hipLaunchKernelGGL((trace_kernel<1, 4, true>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
-        else hipLaunchKernelGGL((trace_kernel<1, 4, false>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
-    } else {
-        if (counters) hipLaunchKernelGGL((trace_kernel<2, 8, true>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
-        else hipLaunchKernelGGL((trace_kernel<2, 8, false>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
+    if (wide_runs) {   // one sample per lane, one wave per workgroup
+        const dim3 grid((sw + 7u) / 8u, (sh + 7u) / 8u, 1u);
+        if (counters) hipLaunchKernelGGL((trace_kernel<1, 4, true, 1>), grid, dim3(64), lds, stream, sc, fr, samples, counters);
+        else hipLaunchKernelGGL((trace_kernel<1, 4, false, 1>), grid, dim3(64), lds, stream, sc, fr, samples, counters);
+    } else {           // two samples per lane, four waves per workgroup
+        const dim3 grid((sw + 31u) / 32u, (sh + 15u) / 16u, 1u);
+        if (counters) hipLaunchKernelGGL((trace_kernel<2, 8, true, 4>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
+        else hipLaunchKernelGGL((trace_kernel<2, 8, false, 4>), grid, dim3(256), lds, stream, sc, fr, samples, counters);
     }
     return hipGetLastError();
 }
