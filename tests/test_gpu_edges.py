@@ -1,0 +1,77 @@
+"""Edge cases of the render path against the oracle: many lights (the reference's GL path stops at 16, its CPU path
+does not: /root/reference/source/scene.cpp:53-62), large SSAA kernels, iteration caps that leave rays unconverged,
+one-pixel and one-row frames, loose tolerances, the deepest nesting the device walkers take."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+LIST, SPHERE, BOX, CROSS = 0, 1, 2, 3
+
+BASE = open(scene_path("menger2.txt")).read()
+
+
+def _frame_pair(rm, oracle, renderer, text, **kw):
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(text=text))
+    gpu = renderer.render_f32()
+    cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
+    return gpu, cpu
+
+
+def test_twenty_lights(rm, oracle, renderer):
+    rng = np.random.default_rng(3)
+    lights = "".join(f"Light {x:.3f} {y:.3f} {z:.3f}\n" for x, y, z in rng.uniform([-50, 30, -80], [50, 60, 0], (18, 3)))
+    gpu, cpu = _frame_pair(rm, oracle, renderer, BASE + "\n" + lights, width=96, height=64, kernel=1)
+    assert gpu.tobytes() == cpu.tobytes()
+
+
+@pytest.mark.parametrize("kw", [dict(width=40, height=30, kernel=5), dict(width=1, height=1, kernel=3), dict(width=257, height=1, kernel=2),
+                                dict(width=3, height=129, kernel=1), dict(width=64, height=48, kernel=2, iterations=7),
+                                dict(width=64, height=48, kernel=1, iterations=1), dict(width=48, height=32, kernel=2, iterations=0),
+                                dict(width=64, height=48, kernel=2, surface_eps=0.05, offset_eps=0.2),
+                                dict(width=64, height=48, kernel=1, saturation=0.5)])
+def test_unusual_parameters(rm, oracle, renderer, kw):
+    gpu, cpu = _frame_pair(rm, oracle, renderer, BASE, **kw)
+    assert gpu.shape == (kw["height"], kw["width"], 4)
+    assert gpu.tobytes() == cpu.tobytes()
+
+
+def test_camera_inside_and_looking_away(rm, oracle, renderer):
+    """A camera inside the sponge's bounding box looking along an axis (ties between symmetric crosses), and one
+    that looks straight up (rays that only ever meet the room)."""
+    inside = BASE.replace("Camera Position 50.0 35.0 -2.5", "Camera Position 0.0 10.0 -50.0").replace(
+        "Camera Direction -1.0 -0.5 -1.0", "Camera Direction 0.0 0.0 -1.0")
+    up = BASE.replace("Camera Direction -1.0 -0.5 -1.0", "Camera Direction 0.0 1.0 0.001")
+    for text in (inside, up):
+        assert text != BASE
+        gpu, cpu = _frame_pair(rm, oracle, renderer, text, width=80, height=60, kernel=2)
+        assert gpu.tobytes() == cpu.tobytes()
+
+
+def _nested(rm_node, depth):
+    f3 = C.c_float * 3
+    zero = f3(0, 0, 0)
+    nodes = []
+    for d in range(depth):
+        nodes.append(rm_node(LIST, d % 4, 2 if d + 1 < depth else 1, zero, zero, zero))
+        nodes.append(rm_node(SPHERE, 0, 0, f3(1.5 * d, 0.5 * d, -d), f3(2.0 + 0.25 * d, 0, 0), f3(0.1 * d, 1, 1)))
+    return nodes
+
+
+def test_deepest_nesting_and_one_level_more(rm, oracle, renderer):
+    """The root list plus 8 nested levels is the limit of the device walkers; one more is refused with a message."""
+    ident = np.eye(4, dtype=np.float32).T.reshape(-1)
+    pts = np.random.default_rng(4).uniform(-14, 14, (4000, 3)).astype(np.float32)
+    ok = _nested(rm.Node, 9)
+    renderer.set_scene_raw(ok, np.zeros((0, 3), np.float32), ident, 1.0)
+    sd, _, sd_march = renderer.eval_sdf_both(pts)
+    osd, _ = oracle.Scene(nodes=_nested(oracle.Node, 9)).sdf(pts)
+    assert sd.tobytes() == osd.tobytes() and sd_march.tobytes() == osd.tobytes()
+    with pytest.raises(rm.RaymarchError, match="nested deeper"):
+        renderer.set_scene_raw(_nested(rm.Node, 10), np.zeros((0, 3), np.float32), ident, 1.0)
+    renderer.set_scene_raw(ok, np.zeros((0, 3), np.float32), ident, 1.0)   # the context is still usable
