@@ -223,6 +223,10 @@ int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_
 int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int counting, char *buffer, size_t capacity,
                      size_t *length);
 int rm_kernel_source_compiles(const char *source);
+/* Process-wide: keeps compiled code objects in `directory` (an existing, writable directory) so that
+ * later processes load them instead of compiling (0.3-1.3 s per scene).  NULL or "" turns it off (the
+ * default).  A file is used only if the source and device headers stored in it equal the current ones. */
+int rm_set_kernel_cache_dir(const char *directory);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

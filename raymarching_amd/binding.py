@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -85,6 +85,7 @@ def lib():
     L.rm_set_evaluator.argtypes = [vp, C.c_int]
     L.rm_kernel_source.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rm_kernel_source_compiles.argtypes = [C.c_char_p]
+    L.rm_set_kernel_cache_dir.argtypes = [C.c_char_p]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
     L.rm_get_tile_costs.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -173,6 +174,11 @@ def kernel_source(scene, lattice=True, counting=False):
     buf = C.create_string_buffer(n.value + 1)
     _check(lib().rm_kernel_source(arr, len(arr), 1 if lattice else 0, int(counting), buf, n.value + 1, C.byref(n)), "rm_kernel_source")
     return buf.value.decode()
+
+
+def set_kernel_cache_dir(path):
+    """Directory for compiled code objects shared between processes (None: off)."""
+    _check(lib().rm_set_kernel_cache_dir(os.fsencode(path) if path else None), "rm_set_kernel_cache_dir")
 
 
 def kernel_source_compiles(source):

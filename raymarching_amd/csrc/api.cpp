@@ -465,6 +465,11 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
     return RM_OK;
 }
 
+int rm_set_kernel_cache_dir(const char *directory) {
+    rmdev::set_kernel_cache_dir(directory);
+    return RM_OK;
+}
+
 int rm_kernel_source_compiles(const char *source) {
     if (!source) return fail(RM_ERR_INVALID, "rm_kernel_source_compiles: null source");
     std::string log;

@@ -6,7 +6,10 @@
 
 #include <hip/hiprtc.h>
 
+#include <unistd.h>
+
 #include <chrono>
+#include <cstdio>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -19,6 +22,60 @@ namespace {
 using CodeObject = std::shared_ptr<const std::vector<char>>;
 std::mutex g_cache_lock;
 std::unordered_map<std::string, CodeObject> g_cache;   // source text -> gfx950 code object
+std::string g_cache_dir;                                // optional second level on disk ("" = none)
+
+// FNV-1a over the source and the embedded headers: names a code object file.  The file also holds
+// the full key text, compared on load, so a hash collision costs a recompile, never a wrong kernel.
+std::string cache_key_text(const std::string &source) {
+    std::string key = source;
+    for (unsigned i = 0; i < kEmbeddedHeaderCount; i++) {
+        key += "\n//@";
+        key += kEmbeddedHeaders[i].name;
+        key += "\n";
+        key += kEmbeddedHeaders[i].text;
+    }
+    return key;
+}
+
+std::string cache_file(const std::string &key) {
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
+    char name[64];
+    std::snprintf(name, sizeof name, "/rm_%016llx.gfx950.bin", h);
+    return g_cache_dir + name;
+}
+
+CodeObject load_from_disk(const std::string &source) {
+    if (g_cache_dir.empty()) return nullptr;
+    const std::string key = cache_key_text(source);
+    std::FILE *f = std::fopen(cache_file(key).c_str(), "rb");
+    if (!f) return nullptr;
+    unsigned long long key_size = 0, code_size = 0;
+    CodeObject result;
+    if (std::fread(&key_size, sizeof key_size, 1, f) == 1 && std::fread(&code_size, sizeof code_size, 1, f) == 1 &&
+        key_size == key.size() && code_size > 0 && code_size < (1ull << 30)) {
+        std::string stored(key_size, '\0');
+        auto code = std::make_shared<std::vector<char>>(code_size);
+        if (std::fread(&stored[0], 1, key_size, f) == key_size && stored == key &&
+            std::fread(code->data(), 1, code_size, f) == code_size)
+            result = code;
+    }
+    std::fclose(f);
+    return result;
+}
+
+void store_to_disk(const std::string &source, const std::vector<char> &code) {
+    if (g_cache_dir.empty()) return;
+    const std::string key = cache_key_text(source), path = cache_file(key), tmp = path + ".tmp" + std::to_string((long long)getpid());
+    std::FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;   // an unwritable cache directory only costs the next process a compile
+    const unsigned long long key_size = key.size(), code_size = code.size();
+    const bool ok = std::fwrite(&key_size, sizeof key_size, 1, f) == 1 && std::fwrite(&code_size, sizeof code_size, 1, f) == 1 &&
+                    std::fwrite(key.data(), 1, key.size(), f) == key.size() && std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    std::fclose(f);
+    if (ok) std::rename(tmp.c_str(), path.c_str());   // atomic: readers see a whole file or none
+    else std::remove(tmp.c_str());
+}
 
 CodeObject build_code_object(const std::string &source, std::string &log) {
     std::vector<const char *> texts, names;
@@ -63,7 +120,17 @@ void SceneModule::unload() {
     *this = SceneModule();
 }
 
-bool check_scene_source(const std::string &source, std::string &log) { return build_code_object(source, log) != nullptr; }
+void set_kernel_cache_dir(const char *dir) {
+    std::lock_guard<std::mutex> hold(g_cache_lock);
+    g_cache_dir = dir ? dir : "";
+}
+
+bool check_scene_source(const std::string &source, std::string &log) {
+    if (load_from_disk(source)) return true;
+    const CodeObject code = build_code_object(source, log);
+    if (code) store_to_disk(source, *code);
+    return code != nullptr;
+}
 
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
                           std::string &log) {
@@ -77,8 +144,12 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, u
     double seconds = 0.0;
     if (!code) {
         const auto t0 = std::chrono::steady_clock::now();
-        code = build_code_object(source, log);
-        if (!code) return false;
+        code = load_from_disk(source);
+        if (!code) {
+            code = build_code_object(source, log);
+            if (!code) return false;
+            store_to_disk(source, *code);
+        }
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> hold(g_cache_lock);
         g_cache.emplace(source, code);

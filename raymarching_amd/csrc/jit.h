@@ -34,6 +34,10 @@ struct SceneModule {
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
                           std::string &log);
 
+// Second-level cache of code objects on disk (null or "": none, the default).  Files are keyed by the
+// generated source and the device headers, written atomically, and verified against the full key on load.
+void set_kernel_cache_dir(const char *dir);
+
 // The compile step alone (no device needed): true if `source` compiles for gfx950.
 bool check_scene_source(const std::string &source, std::string &log);
 

@@ -25,3 +25,29 @@ def test_counting_variant_and_compile_errors(rm):
     with pytest.raises(rm.RaymarchError) as e:
         rm.kernel_source_compiles(counted.replace("single_sd<", "no_such_function<", 1))
     assert "no_such_function" in str(e.value)
+
+
+def test_code_objects_are_kept_on_disk_when_asked(rm, tmp_path):
+    import time
+    src = rm.kernel_source(rm.Scene(scene_path("menger2.txt")))
+    rm.set_kernel_cache_dir(str(tmp_path))
+    try:
+        t0 = time.perf_counter()
+        rm.kernel_source_compiles(src)
+        first = time.perf_counter() - t0
+        files = list(tmp_path.iterdir())
+        assert len(files) == 1 and files[0].name.endswith(".gfx950.bin") and files[0].stat().st_size > 10000
+        t0 = time.perf_counter()
+        rm.kernel_source_compiles(src)
+        assert time.perf_counter() - t0 < first / 5          # loaded, not compiled
+        # a damaged file is not trusted: the key stored in it no longer matches, so the source is compiled again
+        data = bytearray(files[0].read_bytes())
+        data[40] ^= 0xFF
+        files[0].write_bytes(bytes(data))
+        t0 = time.perf_counter()
+        rm.kernel_source_compiles(src)
+        assert time.perf_counter() - t0 > first / 5
+        rm.kernel_source_compiles(src.replace("rm_eval_sdf", "rm_eval_sdf2"))   # another source, another file
+        assert len(list(tmp_path.iterdir())) == 2
+    finally:
+        rm.set_kernel_cache_dir(None)
