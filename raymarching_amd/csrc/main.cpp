@@ -5,6 +5,7 @@
 //
 //   raymarch [--scene scene/objects.txt] [--width 1024] [--height 768] [--ssaa 3] [--iterations 1000]
 //            [--frames 1] [--out out_gpu.png] [--raw out_gpu.rgba] [--exhaustive] [--interpreted]
+//            [--kernel-cache DIR]
 //
 // The CPU renders of the reference's main() (render::CPU / render::OMP) are not part of this
 // library; their lines are printed as "not built" so that the report keeps its shape.
@@ -28,7 +29,7 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 int usage(const char *argv0) {
     std::cout << "usage: " << argv0
               << " [--scene PATH] [--width W] [--height H] [--ssaa K] [--iterations N] [--frames N]\n"
-                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted]\n";
+                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted] [--kernel-cache DIR]\n";
     return 2;
 }
 
@@ -53,6 +54,7 @@ int main(int argc, char **argv) {
         else if (a == "--frames") frames = std::atoi(v);
         else if (a == "--out") out_png = v;
         else if (a == "--raw") out_raw = v;
+        else if (a == "--kernel-cache") rm_set_kernel_cache_dir(v);
         else return usage(argv[0]);
     }
     if (frames < 1) frames = 1;
