@@ -187,7 +187,9 @@ int rm_set_evaluator(rm_context *ctx, int evaluator);
  *                          literals -- compiles it for gfx950 with hiprtc and renders with that
  *                          kernel; code objects are cached per process by source text.
  *                          rm_set_scene fails if the compile fails (no silent fallback);
- *   RM_KERNEL_INTERPRETED  one ahead-of-time kernel walks the scene's record stream.
+ *   RM_KERNEL_INTERPRETED  one ahead-of-time kernel walks the scene's record stream.  The mode
+ *                          for geometry that changes every frame (camera, lights and parameters
+ *                          are data in both modes and never cause a compile).
  * Both give bit-identical frames.  With work counting enabled each mode runs its own counting
  * variant (compiled lazily at the first counted render), so prim_evals and flops_executed are
  * those of the mode: the compiled kernels skip work the interpreted one does.  Takes effect

@@ -152,6 +152,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, u
         }
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> hold(g_cache_lock);
+        if (g_cache.size() >= 256) g_cache.clear();   // a caller that streams ever-new scenes should not grow without bound
         g_cache.emplace(source, code);
     }
     hipError_t e = hipModuleLoadData(&out.module, code->data());
