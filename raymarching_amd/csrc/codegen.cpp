@@ -140,7 +140,28 @@ struct Emitter {
                           "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<true, false>(lds.lattice + %uu, (ConstIndex)sc.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], evals_unused[n]);\n",
                           r.a[1], r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
         } else {
-            std::snprintf(buf, sizeof buf, "    lattice_sd<COUNT, NP>(lds.lattice + %uu, (ConstIndex)sc.lattice + %uu, %uu, %uu, p, %s, work);\n", r.a[1], r.a[1], r.a[0], r.prim,
+            // the lattice's header fields go into the code as literals, its levels are unrolled
+            const uint32_t off = r.a[1], levels = r.a[0];
+            const uint32_t *w = prog.lattice.data() + off;
+            std::snprintf(buf, sizeof buf,
+                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) {\n"
+                          "        const uint32_t *w = lds.lattice + %uu;\n        const ConstIndex g = (ConstIndex)sc.lattice + %uu;\n"
+                          "        const float eps = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + %s);\n"
+                          "        float run = %s[n];\n        uint32_t evals = 0;\n        do {\n",
+                          off, off, lit(as_float(w[2])).c_str(), acc(depth).c_str());
+            s += buf;
+            uint32_t n = 1;
+            for (uint32_t l = 0; l < levels; l++, n *= 3) {
+                std::snprintf(buf, sizeof buf,
+                              "            if (!lattice_level<%u, COUNT>(w + %uu, w, g, %uu, %s, %s, %s, %s, %s, p[n], eps, run, evals)) break;\n", n,
+                              w[kLatOffset + l], levels, lit(as_float(w[kLatHalf + l])).c_str(), lit(as_float(w[kLatInvSpacing + l])).c_str(),
+                              lit(as_float(w[kLatOrigin + 3 * l])).c_str(), lit(as_float(w[kLatOrigin + 3 * l + 1])).c_str(),
+                              lit(as_float(w[kLatOrigin + 3 * l + 2])).c_str());
+                s += buf;
+            }
+            std::snprintf(buf, sizeof buf,
+                          "        } while (false);\n        %s[n] = run;\n"
+                          "        if (COUNT) { work[n].evals += evals; work[n].flops += kFlopsCross * evals; }\n    }\n",
                           acc(depth).c_str());
         }
         s += buf;

@@ -495,6 +495,45 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, ui
     acc = run;
 }
 
+// One level of lattice_fold with everything about the level known when the kernel is compiled (the
+// kernels generated for one scene pass the header fields as literals): N = 3^level centres per axis,
+// half-width h, 1 / spacing, the first centre on each axis; `tab` = the level's X table in LDS.
+// Returns false when the walk ends here.  The rare general case (p deep inside material) hands over
+// to lattice_fold, which repeats the earlier levels to no effect (max is idempotent, and they pass
+// its early-out because coarser levels have larger half-widths).
+template <int N, bool COUNT>
+__device__ __forceinline__ bool lattice_level(const uint32_t *tab, const uint32_t *w, ConstIndex g, uint32_t levels, float h,
+                                              float inv, float x0, float y0, float z0, V3 p, float eps, float &run,
+                                              uint32_t &n_evals) {
+    if (!(run < h * 1.00001f + eps)) return false;
+    const float tau = eps - run;
+    if (!((h + tau) * inv <= 0.45f)) {
+        uint32_t no_prim = kNoPrim;
+        lattice_fold<false, COUNT>(w, g, levels, 0u, p, run, no_prim, n_evals);
+        return false;
+    }
+    const float *X = (const float *)tab, *Y = X + N, *Z = Y + N;
+    const uint32_t *ONES = tab + 3 * N;
+    if (COUNT) n_evals += 3;
+    const int ix = nearest_index(p.x, x0, inv, N - 1), iy = nearest_index(p.y, y0, inv, N - 1), iz = nearest_index(p.z, z0, inv, N - 1);
+    const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
+    const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
+    const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
+    if (bx && by && !(ox & oy)) {
+        run = lattice_row<2>(Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
+        if (COUNT) n_evals += N;
+    }
+    if (bx && bz && !(ox & oz)) {
+        run = lattice_row<1>(Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
+        if (COUNT) n_evals += N;
+    }
+    if (by && bz && !(oy & oz)) {
+        run = lattice_row<0>(X, ONES, N, p.x, h, dy, dz, oy | oz, run);
+        if (COUNT) n_evals += N;
+    }
+    return true;
+}
+
 // lattice_fold at NP points with the work booked (distance-only walk)
 template <bool COUNT, int NP>
 __device__ __forceinline__ void lattice_sd(const uint32_t *w, ConstIndex g, uint32_t levels, uint32_t first_row,

@@ -12,7 +12,7 @@ from conftest import scene_path
 def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
     src = rm.kernel_source(rm.Scene(scene_path(name)), lattice=lattice)
     assert 'extern "C" __global__' in src and "rm_trace" in src and "rm_eval_sdf" in src
-    assert ("lattice_sd<" in src) == (lattice and name != "synthetic1024.txt")
+    assert ("lattice_level<" in src) == (lattice and name != "synthetic1024.txt")
     assert ("fold_run_clustered<" in src) == (name == "synthetic1024.txt")
     rm.kernel_source_compiles(src)
 
