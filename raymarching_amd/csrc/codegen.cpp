@@ -147,22 +147,25 @@ struct Emitter {
                           "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) {\n"
                           "        const uint32_t *w = lds.lattice + %uu;\n        const ConstIndex g = (ConstIndex)sc.lattice + %uu;\n"
                           "        const float eps = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + %s);\n"
-                          "        float run = %s[n];\n        uint32_t evals = 0;\n        do {\n",
+                          "        float run = %s[n];\n        uint32_t evals = 0;\n        int state = kLatticeNext;\n        do {\n",
                           off, off, lit(as_float(w[2])).c_str(), acc(depth).c_str());
             s += buf;
             uint32_t n = 1;
             for (uint32_t l = 0; l < levels; l++, n *= 3) {
                 std::snprintf(buf, sizeof buf,
-                              "            if (!lattice_level<%u, COUNT>(w + %uu, w, g, %uu, %s, %s, %s, %s, %s, p[n], eps, run, evals)) break;\n", n,
-                              w[kLatOffset + l], levels, lit(as_float(w[kLatHalf + l])).c_str(), lit(as_float(w[kLatInvSpacing + l])).c_str(),
+                              "            state = lattice_level<%u, COUNT>(w + %uu, %s, %s, %s, %s, %s, p[n], eps, run, evals);\n"
+                              "            if (state != kLatticeNext) break;\n",
+                              n, w[kLatOffset + l], lit(as_float(w[kLatHalf + l])).c_str(), lit(as_float(w[kLatInvSpacing + l])).c_str(),
                               lit(as_float(w[kLatOrigin + 3 * l])).c_str(), lit(as_float(w[kLatOrigin + 3 * l + 1])).c_str(),
                               lit(as_float(w[kLatOrigin + 3 * l + 2])).c_str());
                 s += buf;
             }
             std::snprintf(buf, sizeof buf,
-                          "        } while (false);\n        %s[n] = run;\n"
+                          "        } while (false);\n"
+                          "        if (state == kLatticeGeneral) { uint32_t no_prim = kNoPrim; lattice_fold<false, COUNT>(w, g, %uu, 0u, p[n], run, no_prim, evals); }\n"
+                          "        %s[n] = run;\n"
                           "        if (COUNT) { work[n].evals += evals; work[n].flops += kFlopsCross * evals; }\n    }\n",
-                          acc(depth).c_str());
+                          levels, acc(depth).c_str());
         }
         s += buf;
     }

@@ -498,20 +498,18 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, ui
 // One level of lattice_fold with everything about the level known when the kernel is compiled (the
 // kernels generated for one scene pass the header fields as literals): N = 3^level centres per axis,
 // half-width h, 1 / spacing, the first centre on each axis; `tab` = the level's X table in LDS.
-// Returns false when the walk ends here.  The rare general case (p deep inside material) hands over
-// to lattice_fold, which repeats the earlier levels to no effect (max is idempotent, and they pass
-// its early-out because coarser levels have larger half-widths).
+// Returns kLatticeNext to go on with the next level, kLatticeDone when the walk ends here, and
+// kLatticeGeneral in the rare case that needs the general scan (p deep inside material): the caller
+// then runs lattice_fold, which repeats the earlier levels to no effect (max is idempotent, and they
+// pass its early-out because coarser levels have larger half-widths).
+constexpr int kLatticeDone = 0, kLatticeNext = 1, kLatticeGeneral = 2;
+
 template <int N, bool COUNT>
-__device__ __forceinline__ bool lattice_level(const uint32_t *tab, const uint32_t *w, ConstIndex g, uint32_t levels, float h,
-                                              float inv, float x0, float y0, float z0, V3 p, float eps, float &run,
-                                              uint32_t &n_evals) {
-    if (!(run < h * 1.00001f + eps)) return false;
+__device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float inv, float x0, float y0, float z0, V3 p, float eps,
+                                             float &run, uint32_t &n_evals) {
+    if (!(run < h * 1.00001f + eps)) return kLatticeDone;
     const float tau = eps - run;
-    if (!((h + tau) * inv <= 0.45f)) {
-        uint32_t no_prim = kNoPrim;
-        lattice_fold<false, COUNT>(w, g, levels, 0u, p, run, no_prim, n_evals);
-        return false;
-    }
+    if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
     const float *X = (const float *)tab, *Y = X + N, *Z = Y + N;
     const uint32_t *ONES = tab + 3 * N;
     if (COUNT) n_evals += 3;
@@ -531,7 +529,7 @@ __device__ __forceinline__ bool lattice_level(const uint32_t *tab, const uint32_
         run = lattice_row<0>(X, ONES, N, p.x, h, dy, dz, oy | oz, run);
         if (COUNT) n_evals += N;
     }
-    return true;
+    return kLatticeNext;
 }
 
 // lattice_fold at NP points with the work booked (distance-only walk)
