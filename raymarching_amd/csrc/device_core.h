@@ -404,6 +404,53 @@ __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONE
     return run;
 }
 
+// Rows of the lanes that have one (`active`), evaluated either by every such lane for itself
+// (lattice_row: all rows at once, n cells deep) or, when few lanes have a long row, one row after
+// the other with the row's n cells dealt out to all lanes that are executing: the owner's operands
+// are broadcast, every lane folds its share of the cells, and the partial maxima meet in one LDS
+// word per wave (a float max is exact and order-free, so the row's result does not depend on who
+// evaluated which cell).  Must be called from control flow that is uniform among the executing
+// lanes; lanes that have left the walk earlier simply are not among the workers.
+__device__ __forceinline__ float *wave_slot() {
+    __shared__ float slots[4];
+    return &slots[threadIdx.x >> 6];
+}
+
+template <int AXIS>
+__device__ __forceinline__ float lattice_rows(bool active, const float *T, const uint32_t *ONES, int n, float pt, float h, float d1,
+                                              float d2, uint32_t fixed_ones, float run) {
+    const unsigned long long rows = __builtin_amdgcn_ballot_w64(active);
+    if (rows == 0) return run;
+    if (n >= 27) {
+        const unsigned long long workers = __builtin_amdgcn_ballot_w64(true);
+        const int n_workers = __builtin_popcountll(workers), n_rows = __builtin_popcountll(rows);
+        // cells per lane: n when every owner walks its own row; per row a share of n plus the exchange otherwise
+        if (n_rows * ((n + n_workers - 1) / n_workers + 6) < n) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(workers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)workers, 0u));
+            const int lane = (int)(threadIdx.x & 63u);
+            float *slot = wave_slot();
+            for (unsigned long long m = rows; m != 0; m &= m - 1) {
+                const int owner = __builtin_ctzll(m);
+                const float o_pt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt), owner));
+                const float o_d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), owner));
+                const float o_d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), owner));
+                const uint32_t o_fixed = (uint32_t)__builtin_amdgcn_readlane((int)fixed_ones, owner);
+                float best = -__builtin_inff();
+                for (int k = rank; k < n; k += n_workers) best = lattice_cell<AXIS>(T[k], ONES[k], o_pt, h, o_d1, o_d2, o_fixed, best);
+                // every lane performs the same three LDS operations in program order (no lane-dependent
+                // branch around them, which the compiler could lay out as two paths in either order)
+                __hip_atomic_store(slot, -__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(slot, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const float row_max = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                run = lane == owner ? __builtin_fmaxf(run, row_max) : run;
+            }
+            return run;
+        }
+    }
+    if (active) run = lattice_row<AXIS>(T, ONES, n, pt, h, d1, d2, fixed_ones, run);
+    return run;
+}
+
 // index of the centre nearest to p (exact enough: see the caller's 0.45-spacing condition)
 __device__ __forceinline__ int nearest_index(float p, float origin, float inv_spacing, int last) {
     const float u = (p - origin) * inv_spacing + 0.5f;
@@ -517,18 +564,11 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
     const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
     const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
-    if (bx && by && !(ox & oy)) {
-        run = lattice_row<2>(Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
-        if (COUNT) n_evals += N;
-    }
-    if (bx && bz && !(ox & oz)) {
-        run = lattice_row<1>(Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
-        if (COUNT) n_evals += N;
-    }
-    if (by && bz && !(oy & oz)) {
-        run = lattice_row<0>(X, ONES, N, p.x, h, dy, dz, oy | oz, run);
-        if (COUNT) n_evals += N;
-    }
+    const bool rz = bx && by && !(ox & oy), ry = bx && bz && !(ox & oz), rx = by && bz && !(oy & oz);
+    run = lattice_rows<2>(rz, Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
+    run = lattice_rows<1>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
+    run = lattice_rows<0>(rx, X, ONES, N, p.x, h, dy, dz, oy | oz, run);
+    if (COUNT) n_evals += (uint32_t)N * ((rz ? 1u : 0u) + (ry ? 1u : 0u) + (rx ? 1u : 0u));
     return kLatticeNext;
 }
 

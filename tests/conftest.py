@@ -44,3 +44,13 @@ def renderer(rm, request):
 
 def scene_path(name):
     return os.path.join(SCENES, name)
+
+
+def same_but_zero_signs(a, b):
+    """True if two float32 arrays are equal bit for bit except that a zero may differ in sign.  The march loop's
+    evaluator may fold equal candidates in another order than the colour-tracking one (cooperative lattice rows);
+    max and min of the same set of floats then agree in everything but the sign of a zero result."""
+    import numpy as np
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))).all())

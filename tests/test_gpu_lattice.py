@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, scene_path
+from conftest import same_but_zero_signs, GOLDEN, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +49,7 @@ def test_lattice_sdf_bitwise(rm, oracle, renderer, levels, pos, size, n_pts):
         try:
             renderer.set_scene(rm.Scene(text=text))
             sd, prim, sd_march = renderer.eval_sdf_both(pts)
-            assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
+            assert same_but_zero_signs(sd_march, sd)   # the march loop's pruning evaluator agrees (zero signs aside)
         finally:
             renderer.set_evaluator(True)
         bad = np.flatnonzero(sd.view(np.uint32) != osd.view(np.uint32))
@@ -76,7 +76,7 @@ def test_near_miss_lists_are_not_lattices_and_stay_exact(rm, oracle, renderer):
         osd, _ = oracle.Scene(nodes=onodes).sdf(pts)
         renderer.set_scene_raw(nodes, lights, ident, 1.0)
         sd, _, sd_march = renderer.eval_sdf_both(pts)
-        assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
+        assert same_but_zero_signs(sd_march, sd)   # the march loop's pruning evaluator agrees (zero signs aside)
         assert sd.tobytes() == osd.tobytes()
 
     def copy(nodes):
@@ -148,7 +148,7 @@ def test_closeup6_points_and_tiny_frame(rm, oracle, renderer):
     rng = np.random.default_rng(6)
     pts = sponge_points(rng, 96, (0, 10, -50), 20.0)
     sd, _, sd_march = renderer.eval_sdf_both(pts)
-    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
+    assert same_but_zero_signs(sd_march, sd)   # the march loop's pruning evaluator agrees (zero signs aside)
     osd, _ = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     kw = dict(width=6, height=4, kernel=1)
@@ -171,7 +171,7 @@ def test_synthetic1024_frame_bit_identical(rm, oracle, renderer):
     assert gpu.tobytes() == cpu.tobytes()
     pts = np.random.default_rng(3).uniform([-70, -2, -120], [70, 40, 20], (5000, 3)).astype(np.float32)
     sd, prim, sd_march = renderer.eval_sdf_both(pts)
-    assert sd_march.tobytes() == sd.tobytes()   # the march loop's pruning evaluator agrees bit for bit
+    assert same_but_zero_signs(sd_march, sd)   # the march loop's pruning evaluator agrees (zero signs aside)
     osd, orgb = orc.sdf(pts)
     assert sd.tobytes() == osd.tobytes()
     colours = np.array([tuple(p.color) for p in orc.flat_prims()], np.float32)
