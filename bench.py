@@ -50,6 +50,7 @@ import raymarching_amd as rm  # noqa: E402
 from raymarching_amd import sharding  # noqa: E402
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet: an FMA in every issue slot; code without fusable multiply-adds tops out near half of it
+VALU_ISSUE_CEILING_T = 69.0            # T lane-instructions/s the 13-instruction cross body sustains (tools/valu_bench.hip)
 WORKLOADS = {
     # name: (scene file, params overrides, description)
     "default": ("default.txt", dict(), "configs[1]: shipped scene (Menger iterations 3), 1024x768, SSAA 3x3, 2 lights"),
@@ -127,8 +128,8 @@ def recorded_traffic(workload, evaluator, kernel_mode):
         if os.path.isfile(path):
             for row in json.load(open(path)):
                 if (row["workload"], row["evaluator"], row["kernel_mode"]) == (workload, evaluator, kernel_mode):
-                    return row["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+                    return row["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), row.get("valu_wave_insts_per_launch")
+    return None, None, None
 
 
 def main():
@@ -293,7 +294,14 @@ def main():
             desc += f" -- EMULATED: rank 0's share of a {a.emulate_share}-way split on one GPU, rate x {a.emulate_share}, no gather"
         # dominant kernel: the trace kernel of rank 0, its own executed flops over its own duration
         achieved = local_exec / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_src = recorded_traffic(a.workload, a.evaluator, a.kernel_mode) if world == 1 else (None, None)
+        traffic, traffic_src, valu_insts = recorded_traffic(a.workload, a.evaluator, a.kernel_mode) if world == 1 else (None, None, None)
+        valu_issue = None
+        if valu_insts:
+            rate = valu_insts * 64 / (kernel_ms * 1e-3) / 1e12
+            valu_issue = {"wave_insts_per_launch": valu_insts, "lane_insts_per_s_T": round(rate, 2), "measured_ceiling_T": VALU_ISSUE_CEILING_T,
+                          "frac_of_ceiling": round(rate / VALU_ISSUE_CEILING_T, 3),
+                          "note": "SQ_INSTS_VALU of a counter run of this workload (same file as traffic) over this run's kernel time, "
+                                  "against the lane-instruction rate tools/valu_bench.hip sustains"}
         line = {
             "metric": "Mrays/s (primary+shadow), default scene", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -307,6 +315,7 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "valu_issue": valu_issue,
                 "kernel_ms": round(kernel_ms, 4), "kernel_ms_in_timed_region": round(overlapped_ms, 4),
                 "kernel_ms_note": "kernel_ms: HIP events around the trace kernel with one frame on the GPU (used for achieved): the "
                                   "timed frames themselves with --frames-in-flight 1, frames rendered just before the timed "

@@ -17,6 +17,7 @@ import os
 ap = argparse.ArgumentParser()
 ap.add_argument("--fetch", required=True)
 ap.add_argument("--write", required=True)
+ap.add_argument("--sq", default=None, help="directory of a pass with SQ_INSTS_VALU (optional): VALU wave-instructions per launch")
 ap.add_argument("--workload", required=True)
 ap.add_argument("--evaluator", required=True)
 ap.add_argument("--kernel-mode", required=True)
@@ -45,6 +46,10 @@ row = {
     "launches_averaged": [n_f, n_w],
     "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
 }
+if a.sq:
+    valu, n_v = per_launch(a.sq, "SQ_INSTS_VALU")
+    row["valu_wave_insts_per_launch"] = int(valu)
+    row["launches_averaged"].append(n_v)
 rows = json.load(open(a.out)) if os.path.isfile(a.out) else []
 rows = [r for r in rows if (r["workload"], r["evaluator"], r["kernel_mode"]) != (a.workload, a.evaluator, a.kernel_mode)]
 rows.append(row)
