@@ -18,6 +18,17 @@ def test_library_exports_every_declared_symbol(rm):
     assert set(rm.exported_symbols()) == declared
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 with nothing but itself."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "raymarch_hip.h"\nint main(void) { rm_params p = { 1024, 768, 3, 1000, 0.05f, 1e-3f, 1e-3f }; '
+                   '(void)p; return RM_OK; }\n')
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                          "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def _flatten_product(nodes):
     """(type, list index, centre, size, colour) per primitive, lists numbered in DFS order."""
     out, modes = [], []
