@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank run with every rank on cuda:0 and the gloo backend: exercises the N > 1 code path "
                          "(sharding, asynchronous gather, assembly) where only one GPU is at hand; its numbers mean nothing")
+    ap.add_argument("--balance", action="store_true",
+                    help="N > 1: re-deal the bands to the ranks by measured cost (off by default: cyclic 4-row bands leave "
+                         "under 2 %% of cost imbalance at N = 8 on the shipped scenes, tools/band_balance.py)")
     ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive-leg", action="store_true")
@@ -189,14 +192,6 @@ def main():
     streams = [torch.cuda.ExternalStream(rr.stream) for rr in rs]
     works = [None] * F
 
-    # ---- work count of this rank's share (counting kernel variant, outside the timed region)
-    r.set_counting(True)
-    r.render_device(rows, None, shard.data_ptr())
-    cnt = r.counters()
-    r.set_counting(False)
-    local_exec = executed_flops(cnt)
-    local_algo = cnt["sdf_calls"] * cnt["flops_per_sdf"] + 7 * cnt["march_steps"]
-
     # ---- per context: one synchronous frame times the tiles, the next ones run in cost order; the trace
     # kernel's duration is taken here, with nothing else on the GPU
     iso = []
@@ -206,6 +201,39 @@ def main():
             if i >= 2:
                 iso.append(rr.counters()["kernel_ms"])
     kernel_ms = sum(iso) / len(iso)
+
+    # ---- cross-GPU balance by measured cost: every rank turns the tile durations it has just measured into a cost
+    # per band, the costs are exchanged, and all ranks compute the same plan that deals the bands -- the same number
+    # to each rank -- so that the summed costs are equal (opt-in: on the shipped scenes cyclic dealing is within 2 % already)
+    band_lists = None
+    if world > 1 and a.balance:
+        import numpy as np
+        tiles = r.tile_costs()
+        side = 8 if tiles.shape[0] * 8 >= local_rows * k else 16
+        mine = sharding.band_costs_from_tiles(tiles, side, k, a.band_rows, rows.band_count)
+        dev = "cpu" if a.rehearse_on_one_gpu else "cuda"
+        mine_t = torch.tensor(mine, dtype=torch.float64, device=dev)
+        every = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(every, mine_t)
+        costs = np.zeros(world * rows.band_count)
+        for q, t in enumerate(every):
+            costs[q::world] = t.cpu().numpy()           # rank q holds image bands q, q + world, ...
+        band_lists = sharding.balanced_band_lists(costs, world)
+        for rr, sh in zip(rs, shards):
+            rr.set_band_list(band_lists[rank])
+            for i in range(3):                          # times the tiles of the new share, then runs in cost order
+                rr.render_device(rows, None, sh.data_ptr())
+        gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
+                                            band_lists=band_lists) for f in range(F)]
+        kernel_ms = rs[0].counters()["kernel_ms"]
+
+    # ---- work count of this rank's share (counting kernel variant, outside the timed region)
+    r.set_counting(True)
+    r.render_device(rows, None, shard.data_ptr())
+    cnt = r.counters()
+    r.set_counting(False)
+    local_exec = executed_flops(cnt)
+    local_algo = cnt["sdf_calls"] * cnt["flops_per_sdf"] + 7 * cnt["march_steps"]
 
     timed_kernel_ms = []
 
@@ -246,6 +274,8 @@ def main():
     # ---- self-check of the sharded path (outside the timed region): the frames gathered on rank 0 must equal
     # the frame one launch renders
     gathered_ok = None
+    for rr in rs:
+        rr.set_band_list(None)
     if world > 1 and rank == 0:
         whole, _ = sharding.band_plan(H, a.band_rows, 1, 0)
         single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
@@ -311,7 +341,7 @@ def main():
                        "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
                        "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
                        "frames_in_flight": F,
-                       "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows}, cyclic over {world} ranks, RCCL gather of RGBA8 to rank 0"},
+                       "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

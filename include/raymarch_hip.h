@@ -71,6 +71,8 @@ typedef struct rm_params {
  * band_rows; the call renders bands first_band, first_band + band_stride, ...
  * (band_count of them) into a compact buffer of band_count * band_rows rows.
  * {height, 0, 1, 1} is the whole frame.  Used to shard one frame over GPUs.
+ * With a band list set (rm_set_band_list) band b of the call is image band list[b] instead, and
+ * band_count must equal the list's length; first_band and band_stride are then ignored.
  */
 typedef struct rm_rows {
     uint32_t band_rows;
@@ -136,6 +138,12 @@ int rm_render_f32(rm_context *ctx, float *host_image);
  * rows = band_count*band_rows.  Work is queued on the context's stream; the
  * call returns after the stream has been synchronised. */
 int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8);
+
+/* Deals arbitrary image bands to this context (e.g. by measured cost, see rm_get_tile_costs): the
+ * device-buffer renders that follow draw band image_bands[b] into rows b * band_rows .. of their
+ * buffers.  count = 0 returns to the arithmetic bands of rm_rows.  Bands beyond the image are left
+ * black.  No counterpart in the reference (one GPU). */
+int rm_set_band_list(rm_context *ctx, const uint32_t *image_bands, uint32_t count);
 
 /*
  * The same without waiting (the reference's render::GPU blocks in glGetTexImage, render.cpp:474;

@@ -90,14 +90,17 @@ struct rm_context {
     struct OrderKey {
         rm_params params;
         rm_rows rows;
-        uint64_t scene_serial;
+        uint64_t scene_serial, band_list_serial;
         uint32_t points_per_lane;
     };
     int tile_scheduling = RM_TILES_BY_COST;
     uint64_t scene_serial = 0;
     OrderKey order_key{};
     bool order_ready = false;
-    uint32_t measured_tiles_x = 0, measured_tiles_y = 0;   // shape of the tile grid d_tile_cost holds
+    uint32_t measured_tiles_x = 0, measured_tiles_y = 0;
+    DeviceArray<uint32_t> d_band_list;
+    uint32_t band_list_size = 0;   // 0: bands are first_band + b * band_stride
+    uint64_t band_list_serial = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
 
     // the frame enqueued last and not yet booked by finish_bands
@@ -143,6 +146,11 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
     RM_HIP(hipSetDevice(ctx->device));
     rmdev::FrameView fr = frame_view(ctx->params, rows);
+    if (ctx->band_list_size) {
+        if (rows.band_count != ctx->band_list_size)
+            return fail(RM_ERR_INVALID, "rm_rows: band_count must equal the length of the band list set with rm_set_band_list");
+        fr.band_list = ctx->d_band_list.ptr;
+    }
     RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
     const bool compiled = ctx->module.loaded();
     const bool wide_runs = ctx->program.run_prims >= 64;
@@ -160,6 +168,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.params = ctx->params;
         key.rows = rows;
         key.scene_serial = ctx->scene_serial;
+        key.band_list_serial = ctx->band_list_size ? ctx->band_list_serial : 0;
         key.points_per_lane = pts;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
@@ -286,7 +295,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
     ctx->module.unload();
     ctx->counting_module.unload();
-    ctx->d_tile_order.release(); ctx->d_tile_cost.release();
+    ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -497,6 +506,19 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode) {
     if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
     ctx->tile_scheduling = mode;
     ctx->order_ready = false;
+    return RM_OK;
+}
+
+int rm_set_band_list(rm_context *ctx, const uint32_t *image_bands, uint32_t count) {
+    if (!ctx || (count && !image_bands)) return fail(RM_ERR_INVALID, "rm_set_band_list: null argument");
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    if (count) {
+        RM_HIP(ctx->d_band_list.reserve(count));
+        RM_HIP(hipMemcpy(ctx->d_band_list.ptr, image_bands, count * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    ctx->band_list_size = count;
+    ctx->band_list_serial++;
     return RM_OK;
 }
 

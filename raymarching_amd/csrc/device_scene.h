@@ -143,6 +143,9 @@ struct FrameView {
     // sorts one frame's costs to start the next frame's expensive tiles first.
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    // Which image band each band of the launch is (null: band b is first_band + b * band_stride): lets
+    // a caller deal bands to GPUs by measured cost instead of cyclically.
+    const uint32_t *band_list;
 };
 
 struct WorkCounters {

@@ -85,7 +85,9 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const V3 origin = camera_view(cam, v3(0.0f, 0.0f, 0.0f), 1.0f);
     const uint32_t ly = sy / k, j = sy - ly * k;   // local pixel row, sub-sample row (inner loop index)
     const uint32_t band = ly / fr.band_rows;
-    const uint32_t pi = (fr.first_band + band * fr.band_stride) * fr.band_rows + (ly - band * fr.band_rows);
+    const uint32_t image_band = fr.band_list ? ((ConstIndex)fr.band_list)[band < fr.band_count ? band : fr.band_count - 1u]
+                                             : fr.first_band + band * fr.band_stride;
+    const uint32_t pi = image_band * fr.band_rows + (ly - band * fr.band_rows);
     const float uv1y = (float)pi * psy, uv2y = (float)(pi + 1u) * psy;
     const float p1y = lerp1(s1y, s2y, uv1y), p2y = lerp1(s1y, s2y, uv2y);
     const float uvy = (float)(j + 1u) / (float)k;

@@ -46,6 +46,42 @@ def assemble(stacked, height, band_rows):
     return g.reshape(-1, width, ch)[:height]
 
 
+def band_costs_from_tiles(tile_costs, tile_side, kernel, band_rows, n_local_bands):
+    """Cost of each of a rank's bands from the per-tile durations of its last tile-timing render
+    (Renderer.tile_costs(): [tiles_y, tiles_x]; a tile row covers tile_side sample rows of the rank's compact
+    sample image, a band band_rows * kernel of them)."""
+    import numpy as np
+
+    per_tile_row = np.asarray(tile_costs, np.float64).sum(axis=1)
+    rows_per_band = band_rows * kernel
+    costs = np.zeros(n_local_bands, np.float64)
+    for t, c in enumerate(per_tile_row):
+        for r in range(t * tile_side, (t + 1) * tile_side):          # the tile row's sample rows, equal shares
+            b = r // rows_per_band
+            if b < n_local_bands:
+                costs[b] += c / tile_side
+    return costs
+
+
+def balanced_band_lists(costs, world):
+    """Deals len(costs) bands (a multiple of world) to `world` ranks, the same number to each, so that the summed
+    costs are as equal as a greedy longest-first assignment makes them.  Returns an int array [world, per_rank]
+    of image band indices, ascending within a rank.  Deterministic: every rank computes the same plan."""
+    import numpy as np
+
+    costs = np.asarray(costs, np.float64)
+    assert len(costs) % world == 0
+    per_rank = len(costs) // world
+    load = np.zeros(world)
+    taken = [[] for _ in range(world)]
+    for b in np.argsort(-costs, kind="stable"):
+        open_ranks = [r for r in range(world) if len(taken[r]) < per_rank]
+        r = min(open_ranks, key=lambda q: (load[q], q))
+        taken[r].append(int(b))
+        load[r] += costs[b]
+    return np.array([sorted(t) for t in taken], np.int64)
+
+
 class FrameGatherer:
     """Gathers one frame's shards to rank 0 without blocking the host, into buffers allocated once.
 
@@ -56,13 +92,20 @@ class FrameGatherer:
     once the stream has reached the copy.
     """
 
-    def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False):
+    def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False, band_lists=None):
         """stage_on_host: gather through host copies, blocking, for backends without device collectives
-        (gloo with GPU shards: rehearsals and tests only)."""
+        (gloo with GPU shards: rehearsals and tests only).
+        band_lists: [world, per_rank] image band indices per rank (balanced_band_lists) when bands are not dealt
+        cyclically; rank r's shard then holds its bands in the order of band_lists[r]."""
         import torch
 
         self.height, self.band_rows, self.world, self.rank = height, band_rows, world, rank
         self.stage_on_host = stage_on_host
+        self.row_index = None
+        if band_lists is not None and world > 1 and rank == 0:
+            lists = torch.as_tensor(band_lists, dtype=torch.int64)
+            rows = (lists.reshape(-1, 1) * band_rows + torch.arange(band_rows).reshape(1, -1)).reshape(-1)
+            self.row_index = rows.to(shard.device)      # frame row of every row of the stacked shards
         self.stack = self.out = None
         if world > 1 and rank == 0:
             self.stack = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
@@ -90,9 +133,12 @@ class FrameGatherer:
             if work is not None:
                 work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
             local_rows, width, ch = self.stack.shape[1:]
-            nb = local_rows // self.band_rows
-            src = self.stack.view(self.world, nb, self.band_rows, width, ch).permute(1, 0, 2, 3, 4)
-            self.out.view(nb, self.world, self.band_rows, width, ch).copy_(src)
+            if self.row_index is not None:
+                self.out.index_copy_(0, self.row_index, self.stack.view(-1, width, ch))
+            else:
+                nb = local_rows // self.band_rows
+                src = self.stack.view(self.world, nb, self.band_rows, width, ch).permute(1, 0, 2, 3, 4)
+                self.out.view(nb, self.world, self.band_rows, width, ch).copy_(src)
         return work
 
     def frame(self):

@@ -317,3 +317,28 @@ def test_queued_frames_on_caller_streams_equal_synchronous_render(rm):
     finally:
         for r in ctxs:
             r.close()
+
+
+def test_band_list_renders_the_listed_bands(rm, renderer):
+    """rm_set_band_list: an arbitrary deal of image bands lands, in list order, in the compact buffer."""
+    import torch
+    p = rm.default_params(width=160, height=90, kernel=2)      # 90 rows: the last band of 4 is ragged
+    renderer.set_params(p)
+    renderer.set_scene(rm.Scene(scene_path("default.txt")))
+    whole = renderer.render_f32()
+    bands = [22, 3, 17, 0, 9, 23]                              # 23 lies partly, 24+ wholly outside the image
+    buf = torch.full((len(bands) * 4, 160, 4), -1.0, dtype=torch.float32, device="cuda")
+    rows = rm.binding.Rows(4, 0, 1, len(bands))
+    renderer.set_band_list(bands)
+    try:
+        for _ in range(2):                                     # natural tile order, then cost order
+            renderer.render_device(rows, buf.data_ptr(), None)
+            got = buf.cpu().numpy()
+            for i, b in enumerate(bands):
+                r0, r1 = b * 4, min(b * 4 + 4, 90)
+                assert np.array_equal(got[i * 4: i * 4 + (r1 - r0)], whole[r0:r1]), f"band {b}"
+        with pytest.raises(rm.RaymarchError, match="band list"):
+            renderer.render_device(rm.binding.Rows(4, 0, 1, 3), buf.data_ptr(), None)
+    finally:
+        renderer.set_band_list(None)
+    assert np.array_equal(renderer.render_f32(), whole)

@@ -37,9 +37,25 @@ def _worker(rank, world, port, height, width, band_rows, out_path):
         for w in works:
             if w is not None:
                 w.wait()
+        # bands dealt by cost instead of cyclically: every rank computes the same plan from the same costs
+        n_bands = world * rows.band_count
+        costs = np.random.default_rng(9).uniform(0, 1, n_bands) ** 3
+        plan = sharding.balanced_band_lists(costs, world)
+        assert sorted(plan.reshape(-1).tolist()) == list(range(n_bands))
+        loads = costs[plan].sum(axis=1)
+        assert loads.max() <= costs[np.arange(n_bands).reshape(-1, world).T].sum(axis=1).max() + 1e-12   # no worse than cyclic
+        dealt = torch.zeros_like(shard)
+        for i, b in enumerate(plan[rank].tolist()):
+            r0, r1 = b * band_rows, min((b + 1) * band_rows, height)
+            if r0 < height:
+                dealt[i * band_rows: i * band_rows + (r1 - r0)] = full[r0:r1]
+        g = sharding.FrameGatherer(dealt, height, band_rows, world, rank, band_lists=plan)
+        w = g.start(dealt)
+        if w is not None:
+            w.wait()
         if rank == 0:
             assert frame.shape == full.shape
-            ok = (frame == full).all().item()
+            ok = (frame == full).all().item() and (g.frame() == full).all().item()
             ok = ok and (gatherers[0].frame() == full).all().item() and (gatherers[1].frame() == 255 - full).all().item()
             np.save(out_path, ok)
         else:

@@ -37,3 +37,34 @@ for band_rows in (1, 2, 4, 8, 16):
     mean = sum(times) / len(times)
     print(f"  band_rows {band_rows:2d}: max {max(times):.3f} mean {mean:.3f} ms  max/mean {max(times) / mean:.3f}  "
           f"speed-up over whole frame {t_whole / max(times):.2f}x", flush=True)
+
+# ---- the same split with the bands re-dealt by measured cost (what bench.py does at N > 1)
+import numpy as np  # noqa: E402
+
+band_rows = 4
+per_rank = sharding.band_plan(p.height, band_rows, world, 0)[0].band_count
+costs = np.zeros(world * per_rank)
+for rank in range(world):
+    rows, local_rows = sharding.band_plan(p.height, band_rows, world, rank)
+    r.set_tile_scheduling(False)
+    r.set_tile_scheduling(True)                       # forget the order: the next render times its tiles
+    r.render_device(rows, None, buf.data_ptr())
+    tiles = r.tile_costs()
+    side = 8 if tiles.shape[0] * 8 >= local_rows * p.kernel else 16
+    costs[rank::world] = sharding.band_costs_from_tiles(tiles, side, p.kernel, band_rows, rows.band_count)
+plan = sharding.balanced_band_lists(costs, world)
+times = []
+rows = rm.binding.Rows(band_rows, 0, 1, per_rank)
+for rank in range(world):
+    r.set_band_list(plan[rank])
+    ms = []
+    for _ in range(5):
+        r.render_device(rows, None, buf.data_ptr())
+        c = r.counters()
+        ms.append(c["kernel_ms"] + c["resolve_ms"])
+    times.append(min(ms))
+r.set_band_list(None)
+mean = sum(times) / len(times)
+print(f"  band_rows {band_rows:2d}, dealt by measured cost: max {max(times):.3f} mean {mean:.3f} ms  max/mean {max(times) / mean:.3f}  "
+      f"(planned cost max/mean {costs[plan].sum(axis=1).max() / costs[plan].sum(axis=1).mean():.3f}, "
+      f"cyclic {max(costs[q::world].sum() for q in range(world)) / (costs.sum() / world):.3f})", flush=True)
