@@ -125,9 +125,9 @@ struct Emitter {
             flops += flops_of_code(code);
         } else if (code == REC_RUN && (r.flags & RUN_CLUSTERED) && !track) {
             std::snprintf(buf, sizeof buf,
-                          "    fold_run_clustered<%s, %s, %s, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, %uu, %uu, %s, %s, p, %s, work);\n",
+                          "    fold_run_clustered<%s, %s, %s, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, %uu, %uu, %s, %s, p, %s, %s, work);\n",
                           kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), r.a[0], r.a[1], tf(r.h[0] != 0u).c_str(), lit(as_float(r.h[2])).c_str(),
-                          acc(depth).c_str());
+                          acc(depth).c_str(), (depth == 0 && !neg && !mx && prog.root_identity > 0) ? "cap" : "no_cap");
         } else if (code == REC_RUN) {
             std::snprintf(buf, sizeof buf,
                           "    fold_run<%s, %s, %s, NP, %s>((ConstRows)sc.pa, (ConstRows)sc.pb, (ConstIndex)sc.row_prim, %uu, %uu, p, %s, %s);\n",
@@ -281,7 +281,7 @@ std::string emit_body(const HostProgram &prog, bool track) {
     std::vector<Item> top;
     parse_children(prog.recs, 0, top);
     e.declare(0, prog.root_identity);
-    if (!track) e.s += "    uint32_t no_prim[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;\n";
+    if (!track) e.s += "    uint32_t no_prim[NP];\n    float no_cap[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { no_prim[n] = kNoPrim; no_cap[n] = __builtin_inff(); }\n    (void)cap;\n";
     else e.s += "    uint32_t evals_unused[NP] = {};\n";
     e.children(top, 0);
     e.s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : "") + " }\n";
@@ -294,7 +294,7 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
     std::string s;
     s += "#include \"trace_kernel.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
-         "                                          float (&out_sd)[NP], Work (&work)[NP]) {\n";
+         "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP]) {\n";
     s += emit_body(prog, false);
     s += "}\n\n";
     s += "template <int NP>\nstatic __device__ __forceinline__ void surface(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"

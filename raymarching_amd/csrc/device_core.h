@@ -252,12 +252,21 @@ __device__ __forceinline__ bool bar_hull_needs_rows(const RowWords ra, V3 p, flo
     return !(__builtin_fmaxf(da, db) - eps >= need);
 }
 
+// `cap`: an upper bound of the value the WHOLE scene will have at p, known to the caller (+inf if
+// none), usable by min-folds at the root of the scene only: a row whose distance is at least cap
+// cannot be the scene's minimum, which lies strictly below cap, so a group that only holds such rows
+// may be skipped even while the accumulator is still larger than cap.
+template <bool NEG>
+__device__ __forceinline__ float capped(float acc, float cap) {
+    return NEG ? acc : __builtin_fminf(acc, cap);
+}
+
 // One listing: rows [base, base + count), then a hull per 8 rows, then (long runs) a hull per 8 hulls.
 // DIR < 0: hulls of the run's own kind; DIR = 0..2: flat bar hulls.
 template <uint32_t KIND, int DIR, bool NEG, bool MAX, int NP>
 __device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_t base, uint32_t count, bool has_supers,
-                                             const V3 (&p)[NP], float (&acc)[NP], const float (&eps)[NP], uint32_t &tested,
-                                             uint32_t &evaluated) {
+                                             const V3 (&p)[NP], float (&acc)[NP], const float (&cap)[NP], const float (&eps)[NP],
+                                             uint32_t &tested, uint32_t &evaluated) {
     uint32_t no_prim[NP];
 #pragma unroll
     for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;
@@ -273,8 +282,8 @@ __device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_
             bool need = false;
 #pragma unroll
             for (int n = 0; n < NP; ++n)
-                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n])
-                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], acc[n], eps[n]));
+                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], capped<NEG>(acc[n], cap[n]), eps[n])
+                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], capped<NEG>(acc[n], cap[n]), eps[n]));
             tested++;
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
             c0 = s * kClusterSize;
@@ -287,8 +296,8 @@ __device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_
             bool need = false;
 #pragma unroll
             for (int n = 0; n < NP; ++n)
-                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], acc[n], eps[n])
-                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], acc[n], eps[n]));
+                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], capped<NEG>(acc[n], cap[n]), eps[n])
+                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], capped<NEG>(acc[n], cap[n]), eps[n]));
             tested++;
             if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
             const uint32_t i0 = c * kClusterSize;
@@ -301,7 +310,8 @@ __device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_
 
 template <uint32_t KIND, bool NEG, bool MAX, int NP, bool COUNT>
 __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count, bool has_supers,
-                                                   float magnitude, const V3 (&p)[NP], float (&acc)[NP], Work (&work)[NP]) {
+                                                   float magnitude, const V3 (&p)[NP], float (&acc)[NP], const float (&cap)[NP],
+                                                   Work (&work)[NP]) {
     static_assert(NEG == MAX, "hulls give lower bounds: only folds that keep small distances can use them");
     float eps[NP];
 #pragma unroll
@@ -311,11 +321,11 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
     if (KIND == K_CROSS || KIND == K_CROSS_ISO) {
         const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
         const uint32_t stride = count + n_clusters + (has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 0u);
-        fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, eps, tested, evaluated);
-        fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, has_supers, p, acc, eps, tested, evaluated);
-        fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, has_supers, p, acc, eps, tested, evaluated);
+        fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, has_supers, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, has_supers, p, acc, cap, eps, tested, evaluated);
     } else {
-        fold_listing<KIND, -1, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, eps, tested, evaluated);
+        fold_listing<KIND, -1, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, cap, eps, tested, evaluated);
     }
     if (COUNT) {
 #pragma unroll
@@ -330,10 +340,13 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
 template <uint32_t KIND, int NP, bool COUNT>
 __device__ __forceinline__ void fold_run_clustered_kind(const SceneView &sc, const RecWords &r, const V3 (&p)[NP],
                                                         float (&acc)[NP], Work (&work)[NP]) {
+    float no_cap[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) no_cap[n] = __builtin_inff();
     if (r[6] & FOLD_MAX)
-        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, work);
+        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, no_cap, work);
     else
-        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, work);
+        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, no_cap, work);
 }
 
 // ---- LATTICE: a complete Menger lattice of cubic crosses, folded with max(s, -cross) ----------

@@ -22,7 +22,8 @@ namespace rmdev {
 struct InterpretedScene {
     template <int NP, bool COUNT>
     static __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
-                                             Work (&work)[NP]) {
+                                             Work (&work)[NP], const float (&cap)[NP]) {
+        (void)cap;   // the record walker does not use the caller's upper bound
         float acc[NP];
         uint32_t no_prim[NP];
     #pragma unroll
