@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--emulate-share", type=int, default=0,
                     help="diagnostic, 1 GPU only: render rank 0's share of an N-way split (no gather); value is "
                          "this one GPU's rate times N, an upper bound for the N-GPU run")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: still form the RCCL group and send every frame through the gather and the "
+                         "assembly (exercises the N > 1 code path's RCCL calls on a single GPU)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank run with every rank on cuda:0 and the gloo backend: exercises the N > 1 code path "
                          "(sharding, asynchronous gather, assembly) where only one GPU is at hand; its numbers mean nothing")
@@ -147,11 +150,15 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(60, exit=True)   # a rehearsal that hangs says where
     torch.cuda.set_device(local)
-    if world > 1:
+    group = world > 1 or a.force_collective       # a process group exists and frames go through the gather
+    if group:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29573")
         if a.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     scene_name, kw, desc = WORKLOADS[a.workload]
     scene_file = os.path.join(ROOT, "scenes", scene_name)
@@ -186,7 +193,8 @@ def main():
         rows, local_rows = sharding.band_plan(H, a.band_rows, a.emulate_share, 0)
     shards = [torch.empty((local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F)]
     shard = shards[0]
-    gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu) for f in range(F)]
+    gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
+                                        always_collective=group) for f in range(F)]
     # every context's own HIP stream, seen from PyTorch (streams the library creates land on distinct hardware
     # queues in creation order; streams of PyTorch's pool do not)
     streams = [torch.cuda.ExternalStream(rr.stream) for rr in rs]
@@ -258,14 +266,14 @@ def main():
     for i in range(a.warmup):
         frame(i)
     drain()
-    if world > 1:
+    if group:
         dist.barrier()
     timed_kernel_ms.clear()
     t0 = time.perf_counter()
     for i in range(a.steps):
         frame(i)
     drain()
-    if world > 1:
+    if group:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
@@ -276,7 +284,7 @@ def main():
     gathered_ok = None
     for rr in rs:
         rr.set_band_list(None)
-    if world > 1 and rank == 0:
+    if group and rank == 0:
         whole, _ = sharding.band_plan(H, a.band_rows, 1, 0)
         single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
         r.render_device(whole, None, single.data_ptr())
@@ -284,7 +292,7 @@ def main():
 
     stats = torch.tensor([elapsed, kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])],
                          dtype=torch.float64, device="cuda")
-    if world > 1:
+    if group:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -341,7 +349,7 @@ def main():
                        "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
                        "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
                        "frames_in_flight": F,
-                       "sharding": "single launch" if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
+                       "sharding": ("single launch" + (", sent through a one-rank RCCL gather" if group else "")) if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -368,7 +376,7 @@ def main():
         print(json.dumps(line), flush=True)
     for rr in rs:
         rr.close()
-    if world > 1:
+    if group:
         dist.destroy_process_group()
 
 

@@ -92,22 +92,25 @@ class FrameGatherer:
     once the stream has reached the copy.
     """
 
-    def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False, band_lists=None):
+    def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False, band_lists=None, always_collective=False):
         """stage_on_host: gather through host copies, blocking, for backends without device collectives
         (gloo with GPU shards: rehearsals and tests only).
+        always_collective: go through the collective and the assembly even when world == 1 (a one-rank group
+        exercises the backend's gather on a machine with a single GPU).
         band_lists: [world, per_rank] image band indices per rank (balanced_band_lists) when bands are not dealt
         cyclically; rank r's shard then holds its bands in the order of band_lists[r]."""
         import torch
 
         self.height, self.band_rows, self.world, self.rank = height, band_rows, world, rank
         self.stage_on_host = stage_on_host
+        self.collective = world > 1 or always_collective
         self.row_index = None
-        if band_lists is not None and world > 1 and rank == 0:
+        if band_lists is not None and self.collective and rank == 0:
             lists = torch.as_tensor(band_lists, dtype=torch.int64)
             rows = (lists.reshape(-1, 1) * band_rows + torch.arange(band_rows).reshape(1, -1)).reshape(-1)
             self.row_index = rows.to(shard.device)      # frame row of every row of the stacked shards
         self.stack = self.out = None
-        if world > 1 and rank == 0:
+        if self.collective and rank == 0:
             self.stack = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
             self.parts = list(self.stack.unbind(0))
             self.out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
@@ -116,7 +119,7 @@ class FrameGatherer:
     def start(self, shard):
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self.collective:
             self.single = shard
             return None
         if self.stage_on_host:
@@ -142,6 +145,6 @@ class FrameGatherer:
         return work
 
     def frame(self):
-        if self.world == 1:
+        if not self.collective:
             return self.single[:self.height]
         return self.out[:self.height] if self.rank == 0 else None
