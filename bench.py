@@ -4,15 +4,19 @@
     python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd|closeup6|synthetic]
                     [--evaluator lattice|exhaustive] [--kernel-mode compiled|interpreted]
 
-A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4; 8 from eight GPUs on),
-each on its own stream, alternate frames: the timed region holds exactly K whole frames, all finished
-(streams drained) before the clock stops.  At N > 1 (one process per GPU, launched by
-torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
-renders its bands into device memory and the RGBA8 bands are gathered to rank 0 with RCCL
-(the one exchange step of the path); the same frame is rendered whatever N is, so scaling
-is "strong".  Rank 0 prints ONE JSON line.
+A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4; 8 on
+two or three GPUs, 16 from four on), each on its own stream, alternate frames: the timed region holds exactly
+K whole frames, all finished and gathered (streams drained) before the clock stops.  At N > 1 (one process per
+GPU, launched by torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
+renders its bands into device memory and the RGBA8 bands are gathered to rank 0 with RCCL (the one exchange
+step of the path), --frames-per-gather frames to a collective; the same frame is rendered whatever N is, so
+scaling is "strong".  Rank 0 prints ONE JSON line.
 
-    value         = frames * W*H*k*k*(1+L) rays / wall time (max over ranks), in Mrays/s
+    value         = frames * W*H*k*k*(1+L) rays / wall time (max over ranks), in Mrays/s: the frame's nominal
+                    ray count (scene.cpp:26-31, 53-62: one camera ray and L shadow rays per sample).  With
+                    --shading coloured (the library's default) samples that end on a surface of colour
+                    (0, 0, 0) do not march their shadow rays, whose result is multiplied by that colour;
+                    mrays_cast_per_s counts the rays actually marched
     roofline      = FLOPs the trace kernel EXECUTED for the frame (its counting variant's tally of the
                     primitive evaluations it executed x FLOPs per primitive + 7 per march step) / its
                     HIP-event duration, against the fp32 vector peak.  The default kernels never visit most
@@ -40,8 +44,11 @@ sys.path.insert(0, ROOT)
 
 # Frames in flight run on one HIP stream each; HIP maps streams onto this many hardware queues per process
 # (its default, 4, would let only four frames overlap).  Read when the runtime starts, hence set before torch.
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# A sharded run keeps up to 16 frames in flight, and the collective's own stream must not share a queue with a
+# frame's: a gather waiting for its frame would hold up the frames queued behind it.
+_QUEUES = 24 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--emulate-share" in sys.argv or "--force-collective" in sys.argv) else 8
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < _QUEUES:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(_QUEUES)
 
 import torch  # noqa: E402  (first: the renderer must share torch's HIP runtime)
 import torch.distributed as dist  # noqa: E402
@@ -70,11 +77,16 @@ def parse():
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="contexts/streams per GPU that alternate frames (default: 4, and 8 on eight GPUs or more, where one "
-                         "rank's share of a frame is short against its longest-running tiles)")
+                    help="contexts/streams per GPU that alternate frames (default: 4; 8 on two or three GPUs and 16 from four on, "
+                         "where one rank's share of a frame is short against its longest-running tiles)")
+    ap.add_argument("--frames-per-gather", type=int, default=0,
+                    help="frames whose shards go to rank 0 in one collective (0: 1 with up to four frames in flight, a quarter of the frames in flight otherwise)")
     ap.add_argument("--emulate-share", type=int, default=0,
                     help="diagnostic, 1 GPU only: render rank 0's share of an N-way split (no gather); value is "
                          "this one GPU's rate times N, an upper bound for the N-GPU run")
+    ap.add_argument("--shading", choices=["coloured", "all"], default="coloured",
+                    help="coloured (the library's default): samples on surfaces of colour (0, 0, 0) skip the normal and the "
+                         "shadow rays, whose product with that colour is zero; all: every sample does the reference's full work")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: still form the RCCL group and send every frame through the gather and the "
                          "assembly (exercises the N > 1 code path's RCCL calls on a single GPU)")
@@ -168,13 +180,20 @@ def main():
     # ---- contexts: one per frame in flight, each on its own stream (frames are independent; the tail of one
     # frame's long-running tiles overlaps the start of the next frame, and the gather of frame i overlaps the
     # render of frame i + 1)
-    F = a.frames_in_flight if a.frames_in_flight > 0 else (8 if max(world, a.emulate_share) >= 8 else 4)
+    # The smaller a rank's share, the more frames it takes to hide one frame's longest tiles.
+    split = max(world, a.emulate_share)
+    F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split == 1 else 8 if split < 4 else 16)
+    # frames per collective: a gather costs ~0.1 ms of host time whatever its size, more than a small share takes to render
+    G = a.frames_per_gather if a.frames_per_gather > 0 else (1 if F <= 4 else F // 4)
+    if F % G:
+        raise SystemExit("--frames-in-flight must be a multiple of --frames-per-gather")
     rs, set_scene_s = [], 0.0
     for f in range(F):
         rr = rm.Renderer(local)
         rr.set_params(params)
         rr.set_evaluator(a.evaluator == "lattice")
         rr.set_kernel_mode(a.kernel_mode == "compiled")
+        rr.set_shading(a.shading == "coloured")
         t0 = time.perf_counter()
         rr.set_scene(scene)
         if f == 0:
@@ -191,14 +210,19 @@ def main():
         if world != 1:
             raise SystemExit("--emulate-share is a single-GPU diagnostic")
         rows, local_rows = sharding.band_plan(H, a.band_rows, a.emulate_share, 0)
-    shards = [torch.empty((local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F)]
+    # Frame slot f renders into slice f % G of batch f // G; a batch's G frames go to rank 0 in one collective,
+    # queued on the stream of the batch's last frame behind the other frames of the batch.
+    def make_gatherers(band_lists=None):
+        return [sharding.FrameGatherer(b, H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
+                                       always_collective=group, band_lists=band_lists) for b in batches]
+    batches = [torch.empty((G, local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F // G)]
+    shards = [batches[f // G][f % G] for f in range(F)]
     shard = shards[0]
-    gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
-                                        always_collective=group) for f in range(F)]
+    gatherers = make_gatherers()
     # every context's own HIP stream, seen from PyTorch (streams the library creates land on distinct hardware
     # queues in creation order; streams of PyTorch's pool do not)
     streams = [torch.cuda.ExternalStream(rr.stream) for rr in rs]
-    works = [None] * F
+    rendered = [torch.cuda.Event() for _ in range(F)]
 
     # ---- per context: one synchronous frame times the tiles, the next ones run in cost order; the trace
     # kernel's duration is taken here, with nothing else on the GPU
@@ -231,8 +255,7 @@ def main():
             rr.set_band_list(band_lists[rank])
             for i in range(3):                          # times the tiles of the new share, then runs in cost order
                 rr.render_device(rows, None, sh.data_ptr())
-        gatherers = [sharding.FrameGatherer(shards[f], H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
-                                            band_lists=band_lists) for f in range(F)]
+        gatherers = make_gatherers(band_lists)
         kernel_ms = rs[0].counters()["kernel_ms"]
 
     # ---- work count of this rank's share (counting kernel variant, outside the timed region)
@@ -245,13 +268,22 @@ def main():
 
     timed_kernel_ms = []
 
-    def frame(i):
+    gathered = set()
+
+    def frame(i, last):
         f = i % F
+        b, slot = divmod(f, G)
         with torch.cuda.stream(streams[f]):
-            if works[f] is not None:
-                works[f].wait()            # the gather of frame i - F has read this shard
+            if group:
+                gatherers[b].wait()            # the batch's previous collective has read this slice
             rs[f].enqueue_device(rows, None, shards[f].data_ptr())
-            works[f] = gatherers[f].start(shards[f])
+            if slot == G - 1 or last:          # the batch is complete (or the loop ends): one collective for its frames,
+                for other in range(b * G, f):  # behind every one of them
+                    streams[f].wait_event(rendered[other])
+                gatherers[b].start(batches[b])
+                gathered.update((b, j) for j in range(slot + 1))
+            elif group:
+                rendered[f].record()
         if F == 1:   # nothing overlaps: every frame's own kernel time can be booked
             rs[0].wait()
             timed_kernel_ms.append(rs[0].counters()["kernel_ms"])
@@ -264,14 +296,16 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        frame(i)
+        frame(i, i == a.warmup - 1)
     drain()
+    gathered.clear()
     if group:
         dist.barrier()
     timed_kernel_ms.clear()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        frame(i)
+        frame(i, i == a.steps - 1)
+    host_issue_ms = (time.perf_counter() - t0) / a.steps * 1e3   # host time to queue a frame (launches, collective)
     drain()
     if group:
         dist.barrier()
@@ -288,9 +322,9 @@ def main():
         whole, _ = sharding.band_plan(H, a.band_rows, 1, 0)
         single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
         r.render_device(whole, None, single.data_ptr())
-        gathered_ok = all(bool(torch.equal(g.frame(), single)) for g in gatherers[:min(F, a.steps + a.warmup)])
+        gathered_ok = all(bool(torch.equal(gatherers[b].frame(j), single)) for b, j in sorted(gathered))
 
-    stats = torch.tensor([elapsed, kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])],
+    stats = torch.tensor([elapsed, kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"]), float(cnt["rays"])],
                          dtype=torch.float64, device="cuda")
     if group:
         mx = stats.clone()
@@ -298,9 +332,9 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, kernel_ms_max = float(mx[0]), float(mx[1])
-        total_exec, total_algo, total_sdf = float(sm[2]), float(sm[3]), float(sm[4])
+        total_exec, total_algo, total_sdf, total_rays = float(sm[2]), float(sm[3]), float(sm[4]), float(sm[5])
     else:
-        kernel_ms_max, total_exec, total_algo, total_sdf = kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"])
+        kernel_ms_max, total_exec, total_algo, total_sdf, total_rays = kernel_ms, float(local_exec), float(local_algo), float(cnt["sdf_calls"]), float(cnt["rays"])
 
     # ---- the reference's algorithm as it stands -- every primitive evaluated at every SDF call -- on the
     # record-walking kernel (rank 0's share, a few frames): executed == algorithmic FLOPs there
@@ -308,7 +342,13 @@ def main():
     if not a.no_exhaustive_leg and cnt["prims"] <= 20000:
         r.set_evaluator(False)
         r.set_kernel_mode(False)
+        r.set_shading(False)                      # and every sample shaded, as the reference does
         r.set_scene(scene)
+        r.set_counting(True)
+        r.render_device(rows, None, shard.data_ptr())
+        cnt_all = r.counters()
+        r.set_counting(False)
+        algo_all = cnt_all["sdf_calls"] * cnt_all["flops_per_sdf"] + 7 * cnt_all["march_steps"]
         for _ in range(2):
             r.render_device(rows, None, shard.data_ptr())
         ms = []
@@ -316,13 +356,15 @@ def main():
             r.render_device(rows, None, shard.data_ptr())
             ms.append(r.counters()["kernel_ms"])
         ex_ms = sum(ms) / len(ms)
-        achieved = local_algo / (ex_ms * 1e-3) / 1e12
-        exhaustive = {"bound": "valu_fp32", "kernel": "trace_kernel (record walker), every primitive visited at every SDF call",
+        achieved = algo_all / (ex_ms * 1e-3) / 1e12
+        exhaustive = {"bound": "valu_fp32", "kernel": "trace_kernel (record walker), every primitive visited at every SDF call, every sample shaded",
+                      "sdf_calls_per_frame": cnt_all["sdf_calls"], "rays_cast_per_frame": cnt_all["rays"],
                       "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(ex_ms, 4),
                       "mrays_per_s": round(rays_per_frame / world / ex_ms / 1e3, 2) if world == 1 else None}
         r.set_evaluator(a.evaluator == "lattice")
         r.set_kernel_mode(a.kernel_mode == "compiled")
+        r.set_shading(a.shading == "coloured")
         r.set_scene(scene)
 
     if rank == 0:
@@ -332,7 +374,7 @@ def main():
             desc += f" -- EMULATED: rank 0's share of a {a.emulate_share}-way split on one GPU, rate x {a.emulate_share}, no gather"
         # dominant kernel: the trace kernel of rank 0, its own executed flops over its own duration
         achieved = local_exec / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_src, valu_insts = recorded_traffic(a.workload, a.evaluator, a.kernel_mode) if world == 1 else (None, None, None)
+        traffic, traffic_src, valu_insts = recorded_traffic(a.workload, a.evaluator, a.kernel_mode) if world == 1 and a.shading == "coloured" else (None, None, None)
         valu_issue = None
         if valu_insts:
             rate = valu_insts * 64 / (kernel_ms * 1e-3) / 1e12
@@ -346,9 +388,13 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": scene_name, "width": W, "height": H, "ssaa_kernel": k,
                        "lights": n_lights, "primitives": cnt["prims"], "rays_per_frame": rays_per_frame,
+                       "rays_cast_per_frame": int(total_rays),
+                       "shading": ("samples on surfaces of colour (0,0,0) skip normal and shadow rays (product with the colour is zero); "
+                                   "value counts the frame's nominal rays, rays_cast_per_frame those marched") if a.shading == "coloured"
+                                  else "every sample (the reference's full work)",
                        "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
                        "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
-                       "frames_in_flight": F,
+                       "frames_in_flight": F, "frames_per_gather": G,
                        "sharding": ("single launch" + (", sent through a one-rank RCCL gather" if group else "")) if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
@@ -367,6 +413,8 @@ def main():
             },
             "gathered_frame_equals_single_launch": gathered_ok,
             "frame_ms": round(ms_per_step, 4),
+            "host_issue_ms_per_frame": round(host_issue_ms, 4),
+            "mrays_cast_per_s": round(total_rays * a.steps / elapsed / 1e6, 3),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }
         if exhaustive:

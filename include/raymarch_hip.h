@@ -223,6 +223,21 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode);
 int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /*
+ * Which samples do the shading work after the camera ray -- the six gradient taps and a shadow ray per
+ * light (scene::raymarch, scene.cpp:26-32).  No counterpart in the reference; the frame is the same
+ * either way.
+ *   RM_SHADE_COLOURED  (default) a sample whose surface colour is (0, 0, 0) -- the wall of `Bounds`
+ *                      behind the scene, 62 % of the shipped frame -- skips them: scene::raymarch
+ *                      returns lighting * colour with the lighting clamped into [saturation, 1]
+ *                      (scene.cpp:60), which is zero for such a sample whatever they give.  Applies
+ *                      while saturation >= 0;
+ *   RM_SHADE_ALL       every sample does the reference's full work: the setting under which the
+ *                      work counters (sdf_calls, march_steps, rays) equal the reference's own counts.
+ */
+typedef enum rm_shading { RM_SHADE_ALL = 0, RM_SHADE_COLOURED = 1 } rm_shading;
+int rm_set_shading(rm_context *ctx, int mode);
+
+/*
  * The compiled mode's two steps without a device or a context (build checks, inspection):
  *   rm_kernel_source           writes the HIP source rm_set_scene would generate for the scene into
  *                              `buffer` (NUL-terminated, truncated to `capacity`) and its full length,

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_set_band_list", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_set_band_list", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -89,6 +89,7 @@ def lib():
     L.rm_set_kernel_cache_dir.argtypes = [C.c_char_p]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
+    L.rm_set_shading.argtypes = [vp, C.c_int]
     L.rm_get_tile_costs.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rm_stream.argtypes = [vp]
@@ -275,6 +276,11 @@ class Renderer:
     def set_tile_scheduling(self, by_cost):
         """True (default): after the first frame of a configuration, expensive tiles are started first."""
         _check(lib().rm_set_tile_scheduling(self._h, 1 if by_cost else 0), "rm_set_tile_scheduling")
+
+    def set_shading(self, coloured_only):
+        """True (default): samples on colourless surfaces skip the gradient taps and shadow rays (their product
+        with the lighting is zero); False: every sample does the reference's full work."""
+        _check(lib().rm_set_shading(self._h, 1 if coloured_only else 0), "rm_set_shading")
 
     def tile_costs(self):
         """[tiles_y, tiles_x] uint32 durations (10 ns ticks) of the last render that timed its tiles."""

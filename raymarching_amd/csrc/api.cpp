@@ -91,9 +91,10 @@ struct rm_context {
         rm_params params;
         rm_rows rows;
         uint64_t scene_serial, band_list_serial;
-        uint32_t points_per_lane;
+        uint32_t points_per_lane, shading;
     };
     int tile_scheduling = RM_TILES_BY_COST;
+    int shading = RM_SHADE_COLOURED;
     uint64_t scene_serial = 0;
     OrderKey order_key{};
     bool order_ready = false;
@@ -151,6 +152,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             return fail(RM_ERR_INVALID, "rm_rows: band_count must equal the length of the band list set with rm_set_band_list");
         fr.band_list = ctx->d_band_list.ptr;
     }
+    fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
     RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
     const bool compiled = ctx->module.loaded();
     const bool wide_runs = ctx->program.run_prims >= 64;
@@ -170,6 +172,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.scene_serial = ctx->scene_serial;
         key.band_list_serial = ctx->band_list_size ? ctx->band_list_serial : 0;
         key.points_per_lane = pts;
+        key.shading = (uint32_t)ctx->shading;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
             pend.by_cost = true;
@@ -506,6 +509,13 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode) {
     if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
     ctx->tile_scheduling = mode;
     ctx->order_ready = false;
+    return RM_OK;
+}
+
+int rm_set_shading(rm_context *ctx, int mode) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (mode != RM_SHADE_ALL && mode != RM_SHADE_COLOURED) return fail(RM_ERR_INVALID, "rm_set_shading: unknown mode");
+    ctx->shading = mode;
     return RM_OK;
 }
 

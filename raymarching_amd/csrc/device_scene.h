@@ -146,6 +146,10 @@ struct FrameView {
     // Which image band each band of the launch is (null: band b is first_band + b * band_stride): lets
     // a caller deal bands to GPUs by measured cost instead of cyclically.
     const uint32_t *band_list;
+    // Nonzero: samples whose surface has no colour skip the normal and the shadow rays (their product with
+    // the lighting is zero either way); zero: every sample does the reference's full work, which is what
+    // work counts that are compared with the reference's need.
+    uint32_t skip_unlit;
 };
 
 struct WorkCounters {

@@ -5,7 +5,7 @@
 //
 //   raymarch [--scene scene/objects.txt] [--width 1024] [--height 768] [--ssaa 3] [--iterations 1000]
 //            [--frames 1] [--out out_gpu.png] [--raw out_gpu.rgba] [--exhaustive] [--interpreted]
-//            [--kernel-cache DIR]
+//            [--kernel-cache DIR] [--shade-all]
 //
 // The CPU renders of the reference's main() (render::CPU / render::OMP) are not part of this
 // library; their lines are printed as "not built" so that the report keeps its shape.
@@ -29,7 +29,7 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 int usage(const char *argv0) {
     std::cout << "usage: " << argv0
               << " [--scene PATH] [--width W] [--height H] [--ssaa K] [--iterations N] [--frames N]\n"
-                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted] [--kernel-cache DIR]\n";
+                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted] [--kernel-cache DIR] [--shade-all]\n";
     return 2;
 }
 
@@ -38,13 +38,14 @@ int usage(const char *argv0) {
 int main(int argc, char **argv) {
     std::string scene_path = "scene/objects.txt", out_png = "out_gpu.png", out_raw;
     int frames = 1;
-    bool exhaustive = false, interpreted = false;
+    bool exhaustive = false, interpreted = false, shade_all = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
         const char *v = nullptr;
         if (a == "--exhaustive") exhaustive = true;
         else if (a == "--interpreted") interpreted = true;
+        else if (a == "--shade-all") shade_all = true;
         else if ((v = value()) == nullptr) return usage(argv[0]);
         else if (a == "--scene") scene_path = v;
         else if (a == "--width") constants::params.width = (uint32_t)std::atoi(v);
@@ -68,6 +69,7 @@ int main(int argc, char **argv) {
     if (!render::ok()) return 1;
     if (exhaustive) rm_set_evaluator(render::context(), RM_EVAL_EXHAUSTIVE);
     if (interpreted) rm_set_kernel_mode(render::context(), RM_KERNEL_INTERPRETED);
+    if (shade_all) rm_set_shading(render::context(), RM_SHADE_ALL);
 
     std::cout << "...Compiling shaders" << std::endl;
     auto t0 = std::chrono::steady_clock::now();

@@ -104,11 +104,13 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const float uvy = (float)(j + 1u) / (float)k;
     const float y = lerp1(p1y, p2y, uvy);
 
-    bool stored[kPts], live[kPts];
+    // live: the sample exists; lit: its colour can depend on the lighting (decided after the camera ray)
+    bool stored[kPts], live[kPts], lit[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
         stored[s] = sx0 + (uint32_t)s < sw && sy < sh;
         live[s] = stored[s] && pi < fr.height;
+        lit[s] = live[s];
     }
 
     // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
@@ -150,7 +152,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         }
 #pragma unroll
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, live, cnt);
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, cnt);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
@@ -158,6 +160,26 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             if (fr.iterations > 0) {
                 float sd_unused[kPts];
                 Scene::template surface<kPts>(sc, lds, at, sd_unused, prim);
+            }
+            // scene::raymarch returns light * colour (scene.cpp:31) with light clamped into [saturation, 1]
+            // (scene.cpp:60): where the surface has no colour (the wall behind the scene, 62 % of the shipped
+            // frame) the product is zero whatever the normal and the shadow rays turn out to be, so those
+            // samples sit out the rest, and a wave of nothing else is finished.
+            if (fr.skip_unlit && fr.saturation >= 0.0f) {
+                bool any = false;
+#pragma unroll
+                for (int s = 0; s < kPts; ++s) {
+                    if (lit[s]) {
+                        bool coloured = false;
+                        if (prim[s] != kNoPrim) {
+                            const Float4 c = sc.colors[prim[s]];
+                            coloured = c.x != 0.0f || c.y != 0.0f || c.z != 0.0f;
+                        }
+                        lit[s] = coloured;
+                    }
+                    any = any || lit[s];
+                }
+                if (__builtin_amdgcn_ballot_w64(any) == 0) break;
             }
             // scene::grad, scene.cpp:70-89: six taps, one evaluator instance
             const float hh = 1e-3f;
@@ -181,7 +203,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                     Scene::template sd<kPts, COUNT>(sc, lds, q, sd, work, no_cap);
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) {
-                        if (COUNT && live[s]) {
+                        if (COUNT && lit[s]) {
                             cnt.sdf++;
                             cnt.evals += work[s].evals;
                             cnt.flops += work[s].flops;

@@ -83,27 +83,35 @@ def balanced_band_lists(costs, world):
 
 
 class FrameGatherer:
-    """Gathers one frame's shards to rank 0 without blocking the host, into buffers allocated once.
+    """Gathers the shards of one frame -- or of a batch of G frames in one collective -- to rank 0 without
+    blocking the host, into buffers allocated once.
 
-    start(shard) issues the gather (asynchronously: the collective is ordered after the work queued so
-    far on the current stream) and, on rank 0, queues the de-interleaving copy behind it; the returned
-    handle's wait() makes the current stream wait for the collective, which is what a rank needs before
-    it overwrites `shard` with the next frame.  frame() is rank 0's assembled [height, W, C] tensor, valid
-    once the stream has reached the copy.
+    start(shard) issues the gather (asynchronously: the collective is ordered after the work queued so far on
+    the current stream), makes the current stream wait for it and, on rank 0, queues the de-interleaving copy
+    behind it.  wait() makes the current stream wait for everything start() queued, which is what a stream
+    needs before it overwrites its part of `shard` with a later frame.  frame(j) is rank 0's assembled
+    [height, W, C] tensor of the batch's j-th frame, valid once the stream has reached the copy.
+
+    One collective costs about 0.1 ms of host time whatever its size; batching G frames per collective keeps
+    that off the critical path when a rank's share of a frame takes less than that to render.
     """
 
     def __init__(self, shard, height, band_rows, world, rank, stage_on_host=False, band_lists=None, always_collective=False):
-        """stage_on_host: gather through host copies, blocking, for backends without device collectives
+        """shard: [local_rows, W, C], or [G, local_rows, W, C] for G frames per collective.
+        stage_on_host: gather through host copies, blocking, for backends without device collectives
         (gloo with GPU shards: rehearsals and tests only).
-        always_collective: go through the collective and the assembly even when world == 1 (a one-rank group
-        exercises the backend's gather on a machine with a single GPU).
         band_lists: [world, per_rank] image band indices per rank (balanced_band_lists) when bands are not dealt
-        cyclically; rank r's shard then holds its bands in the order of band_lists[r]."""
+        cyclically; rank r's shard then holds its bands in the order of band_lists[r].
+        always_collective: go through the collective and the assembly even when world == 1 (a one-rank group
+        exercises the backend's gather on a machine with a single GPU)."""
         import torch
 
         self.height, self.band_rows, self.world, self.rank = height, band_rows, world, rank
         self.stage_on_host = stage_on_host
         self.collective = world > 1 or always_collective
+        self.batched = shard.dim() == 4
+        self.frames = shard.shape[0] if self.batched else 1
+        local_rows, width, ch = shard.shape[-3:]
         self.row_index = None
         if band_lists is not None and self.collective and rank == 0:
             lists = torch.as_tensor(band_lists, dtype=torch.int64)
@@ -111,10 +119,11 @@ class FrameGatherer:
             self.row_index = rows.to(shard.device)      # frame row of every row of the stacked shards
         self.stack = self.out = None
         if self.collective and rank == 0:
-            self.stack = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
-            self.parts = list(self.stack.unbind(0))
-            self.out = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+            self.stack = torch.empty((world, self.frames, local_rows, width, ch), dtype=shard.dtype, device=shard.device)
+            self.parts = [t.view(shard.shape) for t in self.stack.unbind(0)]
+            self.out = torch.empty((self.frames, local_rows * world, width, ch), dtype=shard.dtype, device=shard.device)
         self.single = None
+        self.done = torch.cuda.Event() if shard.is_cuda else None
 
     def start(self, shard):
         import torch.distributed as dist
@@ -129,22 +138,34 @@ class FrameGatherer:
             dist.gather(host, parts, dst=0)
             work = None
             if self.rank == 0:
-                self.stack.copy_(torch.stack(parts))
+                self.stack.copy_(torch.stack(parts).view(self.stack.shape))
         else:
             work = dist.gather(shard, self.parts if self.rank == 0 else None, dst=0, async_op=True)
-        if self.rank == 0:
-            if work is not None:
+            if shard.is_cuda:
                 work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
-            local_rows, width, ch = self.stack.shape[1:]
+        if self.rank == 0:
+            if work is not None and not shard.is_cuda:
+                work.wait()
+            world, frames, local_rows, width, ch = self.stack.shape
             if self.row_index is not None:
-                self.out.index_copy_(0, self.row_index, self.stack.view(-1, width, ch))
+                for j in range(frames):
+                    self.out[j].index_copy_(0, self.row_index, self.stack[:, j].reshape(-1, width, ch))
             else:
                 nb = local_rows // self.band_rows
-                src = self.stack.view(self.world, nb, self.band_rows, width, ch).permute(1, 0, 2, 3, 4)
-                self.out.view(nb, self.world, self.band_rows, width, ch).copy_(src)
+                src = self.stack.view(world, frames, nb, self.band_rows, width, ch).permute(1, 2, 0, 3, 4, 5)
+                self.out.view(frames, nb, world, self.band_rows, width, ch).copy_(src)
+        if self.done is not None:
+            self.done.record()
         return work
 
-    def frame(self):
+    def wait(self):
+        """The current stream waits for what the last start() queued (no-op before the first start and on CPU)."""
+        if self.done is not None and self.collective:
+            import torch
+            torch.cuda.current_stream().wait_event(self.done)
+
+    def frame(self, j=0):
         if not self.collective:
-            return self.single[:self.height]
-        return self.out[:self.height] if self.rank == 0 else None
+            one = self.single[j] if self.batched else self.single
+            return one[:self.height]
+        return self.out[j][:self.height] if self.rank == 0 else None

@@ -51,11 +51,11 @@ def test_two_rank_bench_rehearsal_gathers_the_single_launch_frame(extra):
     import sys
     port = 29700 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
            "--workload", "menger2", "--rehearse-on-one-gpu", "--no-cpu-baseline", "--no-exhaustive-leg"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["gathered_frame_equals_single_launch"] is True
-    assert line["value"] > 0 and line["config"]["frames_in_flight"] == 4
+    assert line["value"] > 0 and line["config"]["frames_in_flight"] == 8 and line["config"]["frames_per_gather"] == 2
     assert ("dealt by measured cost" in line["config"]["sharding"]) == bool(extra)

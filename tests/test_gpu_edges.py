@@ -41,6 +41,25 @@ def test_unusual_parameters(rm, oracle, renderer, kw):
     assert gpu.tobytes() == cpu.tobytes()
 
 
+@pytest.mark.parametrize("saturation", [0.05, 0.0, -0.25])
+def test_colourless_surfaces_in_both_shading_modes(rm, oracle, renderer, saturation):
+    """Samples on a surface of colour (0, 0, 0) may skip normal and shadow rays (rm_set_shading; scene.cpp:31 multiplies
+    the lighting by the colour): a black sphere between coloured bodies, waves that mix both kinds, and lower
+    clamps of the lighting (scene.cpp:60) down to a negative one, under which the shortcut does not apply."""
+    text = BASE.replace("Color 1.0 0.0 0.0", "Color 0.0 0.0 0.0")
+    assert text != BASE
+    kw = dict(width=96, height=72, kernel=2, saturation=saturation)
+    cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(text=text))
+    try:
+        for coloured_only in (True, False):
+            renderer.set_shading(coloured_only)
+            assert renderer.render_f32().tobytes() == cpu.tobytes(), f"coloured_only={coloured_only}"
+    finally:
+        renderer.set_shading(True)
+
+
 def test_camera_inside_and_looking_away(rm, oracle, renderer):
     """A camera inside the sponge's bounding box looking along an axis (ties between symmetric crosses), and one
     that looks straight up (rays that only ever meet the room)."""

@@ -107,10 +107,12 @@ def test_default_frame_both_evaluators_hash(rm, renderer):
         try:
             renderer.set_scene(rm.Scene(scene_path("default.txt")))
             renderer.set_counting(True)
+            renderer.set_shading(False)          # the reference's full work, for the comparison of counts
             img = renderer.render_f32()
             c = renderer.counters()
         finally:
             renderer.set_counting(False)
+            renderer.set_shading(True)
             renderer.set_evaluator(True)
         assert hashlib.sha256(img.tobytes()).hexdigest() == rec["sha256_f32"], f"lattice={lattice}"
         assert c["sdf_calls"] == rec["counters"]["sdf_calls"]

@@ -141,15 +141,23 @@ def test_default_scene_full_frame_hash(rm, renderer):
     renderer.set_params(rm.default_params())
     renderer.set_scene(rm.Scene(scene_path("default.txt")))
     renderer.set_counting(True)
+    renderer.set_shading(False)                  # every sample does the reference's full work: counts compare
     try:
         img = renderer.render_f32()
         c = renderer.counters()
+        renderer.set_shading(True)               # the default: colourless samples skip normal and shadow rays
+        img_default = renderer.render_f32()
+        c_default = renderer.counters()
     finally:
         renderer.set_counting(False)
+        renderer.set_shading(True)
     assert hashlib.sha256(img.tobytes()).hexdigest() == rec["sha256_f32"]
+    assert hashlib.sha256(img_default.tobytes()).hexdigest() == rec["sha256_f32"]
     assert hashlib.sha256(renderer.render_rgba8().tobytes()).hexdigest() == rec["sha256_rgba8"]
     for key in ("sdf_calls", "march_steps", "rays"):
         assert c[key] == rec["counters"][key]
+    # 62.4 % of the frame is the colourless wall: those samples cast no shadow rays
+    assert c_default["rays"] < 0.6 * c["rays"] and c_default["sdf_calls"] < c["sdf_calls"]
 
 
 def test_default_scene_against_reference_png(rm, renderer):
@@ -171,11 +179,13 @@ def test_counters_match_oracle(rm, oracle, renderer):
     renderer.set_params(pp)
     renderer.set_scene(rm.Scene(scene_path("menger2.txt")))
     renderer.set_counting(True)
+    renderer.set_shading(False)
     try:
         renderer.render_f32()
         c = renderer.counters()
     finally:
         renderer.set_counting(False)
+        renderer.set_shading(True)
     _, oc = oracle.Scene(scene_path("menger2.txt")).render(op)
     assert c["rays"] == oc["rays"] == 96 * 72 * 4 * 3
     assert c["march_steps"] == oc["march_steps"]

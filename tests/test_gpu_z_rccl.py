@@ -37,15 +37,13 @@ def test_gather_behind_the_renderers_stream(one_rank_group):
     shards = [torch.zeros((local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in rs]
     gatherers = [sharding.FrameGatherer(s, H, band_rows, 1, 0, always_collective=True) for s in shards]
     streams = [torch.cuda.ExternalStream(r.stream) for r in rs]
-    works = [None, None]
     dist.barrier()
     for i in range(6):
         f = i % 2
         with torch.cuda.stream(streams[f]):
-            if works[f] is not None:
-                works[f].wait()
+            gatherers[f].wait()                         # the previous gather has read this shard
             rs[f].enqueue_device(rows, None, shards[f].data_ptr())
-            works[f] = gatherers[f].start(shards[f])
+            gatherers[f].start(shards[f])
     for r in rs:
         r.wait()
     for s in streams:

@@ -37,6 +37,12 @@ def _worker(rank, world, port, height, width, band_rows, out_path):
         for w in works:
             if w is not None:
                 w.wait()
+        # three frames per collective
+        batch = torch.stack([shard, 255 - shard, shard // 2])
+        gb = sharding.FrameGatherer(batch, height, band_rows, world, rank)
+        wb = gb.start(batch)
+        if wb is not None:
+            wb.wait()
         # bands dealt by cost instead of cyclically: every rank computes the same plan from the same costs
         n_bands = world * rows.band_count
         costs = np.random.default_rng(9).uniform(0, 1, n_bands) ** 3
@@ -57,6 +63,7 @@ def _worker(rank, world, port, height, width, band_rows, out_path):
             assert frame.shape == full.shape
             ok = (frame == full).all().item() and (g.frame() == full).all().item()
             ok = ok and (gatherers[0].frame() == full).all().item() and (gatherers[1].frame() == 255 - full).all().item()
+            ok = ok and all((gb.frame(j) == want).all().item() for j, want in enumerate((full, 255 - full, full // 2)))
             np.save(out_path, ok)
         else:
             assert frame is None and gatherers[0].frame() is None
