@@ -223,16 +223,19 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode);
 int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /*
- * Which samples do the shading work after the camera ray -- the six gradient taps and a shadow ray per
- * light (scene::raymarch, scene.cpp:26-32).  No counterpart in the reference; the frame is the same
- * either way.
+ * How much of the shading work after the camera ray -- the six gradient taps and a shadow ray per
+ * light (scene::raymarch, scene.cpp:26-32) -- is done where it cannot change the frame.  No counterpart
+ * in the reference; the frame is the same either way.
  *   RM_SHADE_COLOURED  (default) a sample whose surface colour is (0, 0, 0) -- the wall of `Bounds`
- *                      behind the scene, 62 % of the shipped frame -- skips them: scene::raymarch
+ *                      behind the scene, 62 % of the shipped frame -- skips all of it: scene::raymarch
  *                      returns lighting * colour with the lighting clamped into [saturation, 1]
- *                      (scene.cpp:60), which is zero for such a sample whatever they give.  Applies
- *                      while saturation >= 0;
- *   RM_SHADE_ALL       every sample does the reference's full work: the setting under which the
- *                      work counters (sdf_calls, march_steps, rays) equal the reference's own counts.
+ *                      (scene.cpp:60), which is zero for such a sample whatever the rays give
+ *                      (applies while saturation >= 0).  And a shadow ray stops marching once it is
+ *                      safely past its light: scene::shadow (scene.cpp:45-50) only asks whether
+ *                      the ray ended before the light, and from there on it cannot come back;
+ *   RM_SHADE_ALL       every sample and every ray does the reference's full work: the setting under
+ *                      which the work counters (sdf_calls, march_steps, rays) equal the reference's
+ *                      own counts.
  */
 typedef enum rm_shading { RM_SHADE_ALL = 0, RM_SHADE_COLOURED = 1 } rm_shading;
 int rm_set_shading(rm_context *ctx, int mode);

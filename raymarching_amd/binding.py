@@ -279,7 +279,8 @@ class Renderer:
 
     def set_shading(self, coloured_only):
         """True (default): samples on colourless surfaces skip the gradient taps and shadow rays (their product
-        with the lighting is zero); False: every sample does the reference's full work."""
+        with the lighting is zero) and shadow rays stop once past their light; False: every sample and ray
+        does the reference's full work."""
         _check(lib().rm_set_shading(self._h, 1 if coloured_only else 0), "rm_set_shading")
 
     def tile_costs(self):

@@ -147,8 +147,8 @@ struct FrameView {
     // a caller deal bands to GPUs by measured cost instead of cyclically.
     const uint32_t *band_list;
     // Nonzero: samples whose surface has no colour skip the normal and the shadow rays (their product with
-    // the lighting is zero either way); zero: every sample does the reference's full work, which is what
-    // work counts that are compared with the reference's need.
+    // the lighting is zero either way) and shadow rays stop once past their light; zero: every sample and
+    // ray does the reference's full work, which is what work counts that are compared with the reference's need.
     uint32_t skip_unlit;
 };
 

@@ -11,9 +11,20 @@ namespace rmdev {
 // scene::surface (scene.cpp:34-42) for the lane's two samples in lockstep: advances p[s]
 // along ray[s] while sample s is live; at[s] is the point of its last SDF evaluation (whose
 // Surface the reference returns).
+//
+// to_light / past_light: a shadow ray only has to tell whether it stops before its light (scene.cpp:45-50:
+// shadowed iff dot(light - end, ray) > 0).  to_light[s] starts as dot(light - p, ray) and goes down by every
+// step's length, so it follows that dot product up to the roundings of the steps; once it is below
+// -past_light[s] the ray is beyond the light for good and the rest of its march cannot change the answer:
+// every later step but the last moves it further on (sd >= surface_eps > 0), and the last one cannot take it
+// back by more than the roundings, because the scene SDF is 1-Lipschitz (see `cap` below), so after a step
+// of length sd its value is at least -roundings.  past_light covers both: 1.8e-7 of the coordinates'
+// magnitude per step for the roundings of p (three components, half an ulp each), 3e-5 of it for the SDF.
+// Camera rays pass to_light = +inf.
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
-                                      const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], LaneCounts &cnt) {
+                                      const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
+                                      const float (&past_light)[kPts], LaneCounts &cnt) {
     bool done[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -45,7 +56,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
                 p[s] = p[s] + ray[s] * sd[s];
                 cap[s] = sd[s] + __builtin_fabsf(sd[s]) * 1.00001f +
                          4e-6f * (__builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(sd[s]));
-                done[s] = sd[s] < fr.surface_eps;
+                to_light[s] -= sd[s];
+                done[s] = sd[s] < fr.surface_eps || to_light[s] < -past_light[s];
                 if (COUNT) {
                     cnt.sdf++;
                     cnt.steps++;
@@ -116,7 +128,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
     // ray to light l (scene::lighting / scene::shadow, scene.cpp:45-62).  One march instance.
     V3 hit[kPts], normal[kPts], p[kPts], ray[kPts], at[kPts];
-    float lighting[kPts];
+    float lighting[kPts], to_light[kPts], past_light[kPts];
     uint32_t prim[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -140,6 +152,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 const float x = lerp1(p1x, p2x, uvx);
                 p[s] = origin;
                 ray[s] = camera_view(cam, normalize3(v3(x, y, -1.0f)), 0.0f);
+                to_light[s] = __builtin_inff();
+                past_light[s] = 0.0f;
             }
         } else {
             const RowWords lp = ((ConstRows)sc.lights)[r - 1];
@@ -148,11 +162,15 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             for (int s = 0; s < kPts; ++s) {
                 ray[s] = normalize3(light - hit[s]);
                 p[s] = hit[s] + normal[s] * lift;
+                to_light[s] = fr.skip_unlit ? dot3(light - p[s], ray[s]) : __builtin_inff();
+                const float scale = __builtin_fabsf(light.x) + __builtin_fabsf(light.y) + __builtin_fabsf(light.z) +
+                                    __builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(to_light[s]);
+                past_light[s] = 0.01f + (1e-4f + 4e-7f * (float)fr.iterations) * scale;
             }
         }
 #pragma unroll
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, cnt);
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];

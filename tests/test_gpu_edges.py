@@ -60,6 +60,26 @@ def test_colourless_surfaces_in_both_shading_modes(rm, oracle, renderer, saturat
         renderer.set_shading(True)
 
 
+def test_lights_in_awkward_places_in_both_shading_modes(rm, oracle, renderer):
+    """Shadow rays may stop once they are past their light (rm_set_shading): lights inside a body, a hair above the
+    floor, outside the room (never passed), next to the camera, and a room ten times the size (longer steps, larger
+    coordinates) must give the oracle's frame with and without that exit."""
+    lights = "Light -9.5 7.0 -25.5\nLight 3.0 0.004 -30.0\nLight 0.0 500.0 0.0\nLight 49.0 34.5 -3.0\nLight 0.0 10.0 -50.0\n"
+    texts = [BASE + "\n" + lights, (BASE + "\n" + lights).replace("Bounds 200.0", "Bounds 2000.0")]
+    assert texts[1] != texts[0]
+    kw = dict(width=80, height=60, kernel=2)
+    for text in texts:
+        cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
+        renderer.set_params(rm.default_params(**kw))
+        renderer.set_scene(rm.Scene(text=text))
+        try:
+            for coloured_only in (True, False):
+                renderer.set_shading(coloured_only)
+                assert renderer.render_f32().tobytes() == cpu.tobytes(), f"coloured_only={coloured_only}"
+        finally:
+            renderer.set_shading(True)
+
+
 def test_camera_inside_and_looking_away(rm, oracle, renderer):
     """A camera inside the sponge's bounding box looking along an axis (ties between symmetric crosses), and one
     that looks straight up (rays that only ever meet the room)."""
