@@ -215,7 +215,10 @@ def main():
     def make_gatherers(band_lists=None):
         return [sharding.FrameGatherer(b, H, a.band_rows, world, rank, stage_on_host=a.rehearse_on_one_gpu,
                                        always_collective=group, band_lists=band_lists) for b in batches]
-    batches = [torch.empty((G, local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(F // G)]
+    # Two sets of batch buffers alternate between rounds of F frames, so that a stream's next frame does not wait
+    # for the collective that is reading its last one.
+    NB = F // G
+    batches = [torch.empty((G, local_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2 * NB)]
     shards = [batches[f // G][f % G] for f in range(F)]
     shard = shards[0]
     gatherers = make_gatherers()
@@ -273,17 +276,18 @@ def main():
     def frame(i, last):
         f = i % F
         b, slot = divmod(f, G)
-        with torch.cuda.stream(streams[f]):
-            if group:
-                gatherers[b].wait()            # the batch's previous collective has read this slice
-            rs[f].enqueue_device(rows, None, shards[f].data_ptr())
-            if slot == G - 1 or last:          # the batch is complete (or the loop ends): one collective for its frames,
-                for other in range(b * G, f):  # behind every one of them
-                    streams[f].wait_event(rendered[other])
+        b += NB * ((i // F) & 1)
+        if group:
+            gatherers[b].wait(streams[f])      # the collective that read this buffer two rounds ago
+        rs[f].enqueue_device(rows, None, batches[b][slot].data_ptr())     # on the context's own stream, streams[f]
+        if slot == G - 1 or last:              # the batch is complete (or the loop ends): one collective for its frames,
+            for other in range(f - slot, f):   # behind every one of them
+                streams[f].wait_event(rendered[other])
+            with torch.cuda.stream(streams[f]):
                 gatherers[b].start(batches[b])
-                gathered.update((b, j) for j in range(slot + 1))
-            elif group:
-                rendered[f].record()
+            gathered.update((b, j) for j in range(slot + 1))
+        elif group:
+            rendered[f].record(streams[f])
         if F == 1:   # nothing overlaps: every frame's own kernel time can be booked
             rs[0].wait()
             timed_kernel_ms.append(rs[0].counters()["kernel_ms"])
@@ -380,8 +384,11 @@ def main():
             rate = valu_insts * 64 / (kernel_ms * 1e-3) / 1e12
             valu_issue = {"wave_insts_per_launch": valu_insts, "lane_insts_per_s_T": round(rate, 2), "measured_ceiling_T": VALU_ISSUE_CEILING_T,
                           "frac_of_ceiling": round(rate / VALU_ISSUE_CEILING_T, 3),
-                          "note": "SQ_INSTS_VALU of a counter run of this workload (same file as traffic) over this run's kernel time, "
-                                  "against the lane-instruction rate tools/valu_bench.hip sustains"}
+                          "frac_of_ceiling_frames_in_flight": round(valu_insts * 64 / (ms_per_step * 1e-3) / 1e12 / VALU_ISSUE_CEILING_T, 3)
+                                                              if a.emulate_share <= 1 else None,
+                          "note": "SQ_INSTS_VALU of a counter run of this workload (same file as traffic) over this run's kernel time "
+                                  "(one frame alone on the GPU, bounded by its longest tiles) and over the time per frame "
+                                  "with frames in flight, against the lane-instruction rate tools/valu_bench.hip sustains"}
         line = {
             "metric": "Mrays/s (primary+shadow), default scene", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -158,11 +158,14 @@ class FrameGatherer:
             self.done.record()
         return work
 
-    def wait(self):
-        """The current stream waits for what the last start() queued (no-op before the first start and on CPU)."""
+    def wait(self, stream=None):
+        """`stream` (default: the current one) waits for what the last start() queued (no-op before the first
+        start and on CPU)."""
         if self.done is not None and self.collective:
-            import torch
-            torch.cuda.current_stream().wait_event(self.done)
+            if stream is None:
+                import torch
+                stream = torch.cuda.current_stream()
+            stream.wait_event(self.done)
 
     def frame(self, j=0):
         if not self.collective:
