@@ -406,6 +406,10 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "achieved_frames_in_flight": round(total_exec / (ms_per_step * 1e-3) / 1e12, 3),
+                "frac_frames_in_flight": round(total_exec / (ms_per_step * 1e-3) / 1e12 / (FP32_VECTOR_PEAK_TFLOPS * world), 4),
+                "in_flight_note": "executed FLOPs of a frame over the time per frame of the timed region (all GPUs; resolve and gather included): "
+                                  "the sustained rate when the tails of one frame's longest tiles are filled by other frames",
                 "valu_issue": valu_issue,
                 "kernel_ms": round(kernel_ms, 4), "kernel_ms_in_timed_region": round(overlapped_ms, 4),
                 "kernel_ms_note": "kernel_ms: HIP events around the trace kernel with one frame on the GPU (used for achieved): the "
