@@ -14,6 +14,7 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--scene", default="default")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--exhaustive", action="store_true")
+ap.add_argument("--in-flight", type=int, default=0, help="also time the frame rate with this many contexts alternating frames")
 a = ap.parse_args()
 
 renderers = []
@@ -35,6 +36,32 @@ for rnd in range(a.rounds + 1):
         r.render_rgba8()
         if rnd:
             times[path].append(r.counters()["kernel_ms"])
+if a.in_flight:
+    import time
+    for path, L, r in renderers:
+        binding._lib = L
+        rs = [r]
+        for _ in range(a.in_flight - 1):
+            q = binding.Renderer(0)
+            q.set_params(r.params)
+            q.set_evaluator(not a.exhaustive)
+            q.set_scene(binding.Scene(os.path.join(ROOT, "scenes", a.scene + ".txt")))
+            rs.append(q)
+        rows = binding.Rows(r.params.height, 0, 1, 1)
+        bufs = [torch.empty((r.params.height, r.params.width, 4), dtype=torch.uint8, device="cuda") for _ in rs]
+        for q, b in zip(rs, bufs):
+            for _ in range(3):
+                q.render_device(rows, None, b.data_ptr())
+        best = 1e9
+        for rnd in range(a.rounds):
+            n = 40
+            t0 = time.perf_counter()
+            for i in range(n):
+                rs[i % len(rs)].enqueue_device(rows, None, bufs[i % len(rs)].data_ptr())
+            for q in rs:
+                q.wait()
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        print(f"{os.path.basename(path):28s} {a.in_flight} frames in flight: {best:.4f} ms per frame", flush=True)
 for path, ms in times.items():
     ms.sort()
     print(f"{os.path.basename(path):28s} min {ms[0]:.3f}  median {ms[len(ms) // 2]:.3f}  ms  {[round(m, 2) for m in ms]}", flush=True)
