@@ -80,7 +80,7 @@ def parse():
                     help="contexts/streams per GPU that alternate frames (default: 4; 8 on two or three GPUs and 16 from four on, "
                          "where one rank's share of a frame is short against its longest-running tiles)")
     ap.add_argument("--frames-per-gather", type=int, default=0,
-                    help="frames whose shards go to rank 0 in one collective (0: 1 with up to four frames in flight, a quarter of the frames in flight otherwise)")
+                    help="frames whose shards go to rank 0 in one collective (default 1)")
     ap.add_argument("--emulate-share", type=int, default=0,
                     help="diagnostic, 1 GPU only: render rank 0's share of an N-way split (no gather); value is "
                          "this one GPU's rate times N, an upper bound for the N-GPU run")
@@ -183,8 +183,9 @@ def main():
     # The smaller a rank's share, the more frames it takes to hide one frame's longest tiles.
     split = max(world, a.emulate_share)
     F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split == 1 else 8 if split < 4 else 16)
-    # frames per collective: a gather costs ~0.1 ms of host time whatever its size, more than a small share takes to render
-    G = a.frames_per_gather if a.frames_per_gather > 0 else (1 if F <= 4 else F // 4)
+    # frames per collective (one measured best on one GPU: queueing a gather costs the host ~0.03 ms, less than a
+    # rank's share of a default frame takes to render at N = 8, and frames gathered together wait for each other)
+    G = a.frames_per_gather if a.frames_per_gather > 0 else 1
     if F % G:
         raise SystemExit("--frames-in-flight must be a multiple of --frames-per-gather")
     rs, set_scene_s = [], 0.0

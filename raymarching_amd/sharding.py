@@ -86,9 +86,9 @@ class FrameGatherer:
     """Gathers the shards of one frame -- or of a batch of G frames in one collective -- to rank 0 without
     blocking the host, into buffers allocated once.
 
-    start(shard) issues the gather (asynchronously: the collective is ordered after the work queued so far on
-    the current stream), makes the current stream wait for it and, on rank 0, queues the de-interleaving copy
-    behind it.  wait() makes the current stream wait for everything start() queued, which is what a stream
+    start(shard) issues the gather (with a device backend the call only queues it: the collective is ordered
+    after the work queued so far on the current stream, and the current stream waits for it) and, on rank 0,
+    queues the de-interleaving copy behind it.  wait() makes the current stream wait for everything start() queued, which is what a stream
     needs before it overwrites its part of `shard` with a later frame.  frame(j) is rank 0's assembled
     [height, W, C] tensor of the batch's j-th frame, valid once the stream has reached the copy.
 
@@ -140,12 +140,12 @@ class FrameGatherer:
             if self.rank == 0:
                 self.stack.copy_(torch.stack(parts).view(self.stack.shape))
         else:
-            work = dist.gather(shard, self.parts if self.rank == 0 else None, dst=0, async_op=True)
-            if shard.is_cuda:
-                work.wait()   # orders the current stream behind the collective; the host does not block on NCCL/RCCL
+            # With NCCL/RCCL the call returns once the collective is queued: it runs on the backend's stream behind
+            # the work queued on the current stream so far, and the current stream waits for it -- the host does not.
+            # (async_op=True plus wait() does the same through a Work object, at 20 us more per call.)
+            dist.gather(shard, self.parts if self.rank == 0 else None, dst=0)
+            work = None
         if self.rank == 0:
-            if work is not None and not shard.is_cuda:
-                work.wait()
             world, frames, local_rows, width, ch = self.stack.shape
             if self.row_index is not None:
                 for j in range(frames):
