@@ -300,6 +300,12 @@ def main():
             st.synchronize()
         torch.cuda.synchronize()
 
+    # set-up, like the tile timing above: every frame slot and both of its buffers carry one frame through the
+    # gather once (first use of a buffer in a collective registers it with the backend), whatever W is
+    if group:
+        for i in range(2 * F):
+            frame(i, i == 2 * F - 1)
+        drain()
     for i in range(a.warmup):
         frame(i, i == a.warmup - 1)
     drain()

@@ -103,6 +103,8 @@ typedef struct rm_counters {
     uint64_t flops_executed; /* algorithmic FLOPs of the primitive evaluations the kernel executed
                               (11 per sphere, 9 per box, 15 per cross; evaluations skipped by a
                               bound or a lattice are not counted), march steps excluded  */
+    uint64_t tile_parts;   /* workgroups of the last render beyond one per tile: in cost order the few
+                              tiles that run longest are launched as 4 or 16 parts           */
 } rm_counters;
 
 typedef struct rm_context rm_context;

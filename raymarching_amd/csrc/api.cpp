@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <cstring>
 #include <new>
@@ -103,10 +104,12 @@ struct rm_context {
     uint32_t band_list_size = 0;   // 0: bands are first_band + b * band_stride
     uint64_t band_list_serial = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
+    uint32_t order_extra = 0;        // entries of d_tile_order beyond one per tile (quarters of the longest tiles)
 
     // the frame enqueued last and not yet booked by finish_bands
     struct Pending {
         bool active = false, measuring = false, by_cost = false, compiled = false, counted = false;
+        bool splittable = false;   // the kernel takes quarter-tile entries (one wave per workgroup, one sample per lane)
         size_t n_tiles = 0;
     };
     Pending pending;
@@ -122,6 +125,8 @@ namespace {
 // sample would double the divergent lattice walks.  128 registers per lane (4 waves per SIMD)
 // avoid all spills.
 constexpr int kCompiledPts = 1, kCompiledWaves = 4;
+constexpr size_t kSplitShare = 64;   // at most one tile in this many is split (counted in quarter splits)
+constexpr double kQuartersFrom = 0.6, kSixteenthsFrom = 0.8;   // shares of the longest tile's duration
 
 int check_ready(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
@@ -175,6 +180,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.shading = (uint32_t)ctx->shading;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
+            fr.extra_slots = ctx->order_extra;
             pend.by_cost = true;
         } else if (may_measure) {
             ctx->order_key = key;
@@ -183,7 +189,8 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->measured_tiles_x = (sw + side * pts - 1u) / (side * pts);
             ctx->measured_tiles_y = (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
-            RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles));
+            pend.splittable = compiled && ctx->module.waves_per_group == 1u && pts == 1u;
+            RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 4u * (pend.n_tiles / kSplitShare + 4u)));
             fr.tile_cost = ctx->d_tile_cost.ptr;
         }
     }
@@ -225,11 +232,36 @@ int finish_bands(rm_context *ctx) {
         RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, pend.n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, order.data(), pend.n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // The frame cannot end before its longest tile does.  Tiles that ran nearly as long as the longest (a handful,
+        // where a few rays take hundreds of expensive steps) are listed as 4 or 16 workgroups, each of which waits only
+        // for its own samples: measured on the shipped frame, 0.86 -> 0.62 ms alone on the GPU with these thresholds;
+        // lower ones split more tiles than the shorter tail pays for.
+        std::vector<uint32_t> entries;
+        entries.reserve(order.size() + 4u * (order.size() / kSplitShare + 4u));
+        size_t n_split = 0;
+        const double longest = order.empty() ? 0.0 : (double)cost[order[0]];
+        const size_t most = order.size() / kSplitShare;   // in units of quarter splits
+        const uint32_t median = order.empty() ? 0u : cost[order[order.size() / 2]];
+        for (uint32_t t : order) {
+            // (a frame of tiles that all take about as long has no tail to shorten: only tiles far above the median)
+            const bool may = pend.splittable && cost[t] > 8u * median && t <= rmdev::kTileMask;
+            if (may && n_split + 4 <= most && (double)cost[t] >= kSixteenthsFrom * longest) {
+                for (uint32_t q = 0; q < 16u; q++) entries.push_back(t | ((q + 5u) << rmdev::kTileBits));
+                n_split += 4;
+            } else if (may && n_split < most && (double)cost[t] >= kQuartersFrom * longest) {
+                for (uint32_t q = 0; q < 4u; q++) entries.push_back(t | ((q + 1u) << rmdev::kTileBits));
+                n_split++;
+            } else {
+                entries.push_back(t);
+            }
+        }
+        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, entries.data(), entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ctx->order_extra = (uint32_t)(entries.size() - order.size());
         ctx->order_ready = true;
     }
     ctx->last = rm_counters{};
     ctx->last.tiles_by_cost = pend.by_cost ? 1u : 0u;
+    ctx->last.tile_parts = pend.by_cost ? ctx->order_extra : 0u;
     ctx->last.kernel_ms = ms_trace;
     ctx->last.resolve_ms = ms_resolve;
     ctx->last.prims = ctx->program.n_prims;

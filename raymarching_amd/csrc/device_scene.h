@@ -131,6 +131,8 @@ struct SceneView {
     const float *camera;    // 16 floats of the column-major camera matrix, then the focal length
 };
 
+constexpr uint32_t kTileBits = 27u, kTileMask = (1u << kTileBits) - 1u;
+
 struct FrameView {
     uint32_t width, height, kernel;
     int32_t iterations;
@@ -141,7 +143,14 @@ struct FrameView {
     // tile_order[b] (tiles numbered row-major over the launch's sample image) instead of tile b, and
     // every workgroup stores how long it ran, in 10 ns ticks, into tile_cost[its tile].  The host
     // sorts one frame's costs to start the next frame's expensive tiles first.
+    // A tile_order entry is a tile number in its low kTileBits bits and, in the bits above, 0 for the whole tile,
+    // 1 + q for quarter q of it (4 x 4 samples on the wave's first 16 lanes) or 5 + s for sixteenth s (2 x 2 samples
+    // on the first 4 lanes): the host lists the few tiles that run longest -- a frame cannot end before they do --
+    // as 4 or 16 workgroups instead of one, which ends them sooner (each part waits only for the slowest of its own
+    // samples at every step).  extra_slots = the number of entries beyond one per tile; the grid has as many more
+    // rows as they take.
     const uint32_t *tile_order;
+    uint32_t extra_slots;
     uint32_t *tile_cost;
     // Which image band each band of the launch is (null: band b is first_band + b * band_stride): lets
     // a caller deal bands to GPUs by measured cost instead of cyclically.

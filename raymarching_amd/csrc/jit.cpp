@@ -195,7 +195,9 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
     FrameView fr_arg = fr;
     void *args[] = { &sc_arg, &fr_arg, &samples, &counters };
     const uint32_t side = m.waves_per_group == 4u ? 16u : 8u;
-    return hipModuleLaunchKernel(m.trace, (sw + side * pts - 1u) / (side * pts), (sh + side - 1u) / side, 1, 64u * m.waves_per_group, 1, 1,
+    const uint32_t tiles_x = (sw + side * pts - 1u) / (side * pts);
+    const uint32_t extra_rows = fr.tile_order ? (fr.extra_slots + tiles_x - 1u) / tiles_x : 0u;
+    return hipModuleLaunchKernel(m.trace, tiles_x, (sh + side - 1u) / side + extra_rows, 1, 64u * m.waves_per_group, 1, 1,
                                  lds_bytes_of(sc), stream, args, nullptr);
 }
 

@@ -82,19 +82,28 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     if (COUNT) {
         if (threadIdx.x < 6) block_counts[threadIdx.x] = 0;
     }
-    const Lds lds = stage_lds(sc);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
-    const unsigned long long started = fr.tile_cost ? wall_clock64() : 0ull;
-    const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t tile = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
-    const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
     // kWaves = 4: a workgroup is 2 x 2 waves of 8 x 8 lanes; kWaves = 1: one wave
     constexpr uint32_t kSide = kWaves == 4 ? 2u : 1u;
-    const uint32_t sx0 = tile_x * (8u * kSide * kPts) + (kWaves == 4 ? (wave & 1u) : 0u) * (8u * kPts) + (lane & 7u) * (uint32_t)kPts;
-    const uint32_t sy = tile_y * (8u * kSide) + (kWaves == 4 ? (wave >> 1) : 0u) * 8u + (lane >> 3);
+    const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t n_tiles = gridDim.x * ((sh + 8u * kSide - 1u) / (8u * kSide));   // gridDim.x = tiles per row
+    if (slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;            // the last grid row's surplus
+    const Lds lds = stage_lds(sc);
+    const unsigned long long started = fr.tile_cost ? wall_clock64() : 0ull;
+    const uint32_t entry = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
+    const uint32_t tile = entry & kTileMask, part = (kWaves == 1 && kPts == 1) ? entry >> kTileBits : 0u;
+    const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
+    // a whole tile: lane = 8 * row + column; quarter q: lanes 0..15 = 4 * row + column in the quarter
+    // part 1..4: quarter part - 1 (4 x 4 samples, lanes 0..15); part 5..20: sixteenth part - 5 (2 x 2 samples, lanes 0..3)
+    const uint32_t six = part - 5u;
+    const uint32_t col = part == 0u ? (lane & 7u) : (part < 5u ? ((part - 1u) & 1u) * 4u + (lane & 3u) : (six & 3u) * 2u + (lane & 1u));
+    const uint32_t row = part == 0u ? (lane >> 3) : (part < 5u ? ((part - 1u) >> 1) * 4u + ((lane >> 2) & 3u) : (six >> 2) * 2u + ((lane >> 1) & 1u));
+    const bool in_part = part == 0u || lane < (part < 5u ? 16u : 4u);
+    const uint32_t sx0 = tile_x * (8u * kSide * kPts) + (kWaves == 4 ? (wave & 1u) : 0u) * (8u * kPts) + col * (uint32_t)kPts;
+    const uint32_t sy = tile_y * (8u * kSide) + (kWaves == 4 ? (wave >> 1) : 0u) * 8u + row;
     LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
@@ -120,7 +129,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     bool stored[kPts], live[kPts], lit[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
-        stored[s] = sx0 + (uint32_t)s < sw && sy < sh;
+        stored[s] = in_part && sx0 + (uint32_t)s < sw && sy < sh;
         live[s] = stored[s] && pi < fr.height;
         lit[s] = live[s];
     }

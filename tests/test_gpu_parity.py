@@ -272,20 +272,25 @@ def test_ties_between_kinds_keep_the_earlier_child(rm, oracle, renderer, mode, c
     np.testing.assert_array_equal(colours[prim], orgb)
 
 
-def test_cost_ordered_tiles_render_the_same_frame(rm, renderer):
-    """The second and later renders of a configuration start expensive tiles first: same bytes, flag set."""
-    renderer.set_params(rm.default_params(width=320, height=200, kernel=2))
+@pytest.mark.parametrize("size", [dict(width=320, height=200, kernel=2), dict(width=163, height=99, kernel=3)], ids=["320x200k2", "163x99k3"])
+def test_cost_ordered_tiles_render_the_same_frame(rm, renderer, size):
+    """The second and later renders of a configuration start expensive tiles first: same bytes, flag set
+    (the second size has ragged tiles at the right and bottom edges)."""
+    renderer.set_params(rm.default_params(**size))
     renderer.set_scene(rm.Scene(scene_path("default.txt")))
     first = renderer.render_f32()
     assert renderer.counters()["tiles_by_cost"] == 0          # the measuring frame runs in natural order
     for _ in range(2):
         again = renderer.render_f32()
-        assert renderer.counters()["tiles_by_cost"] == 1
+        c = renderer.counters()
+        assert c["tiles_by_cost"] == 1
+        # the sponge's longest tiles run as quarters or sixteenths (kernels of one wave per workgroup take such entries)
+        assert (c["tile_parts"] > 0) == (renderer.kernel_mode == "compiled")
         assert again.tobytes() == first.tobytes()
     renderer.set_tile_scheduling(False)
     try:
         natural = renderer.render_f32()
-        assert renderer.counters()["tiles_by_cost"] == 0
+        assert renderer.counters()["tiles_by_cost"] == 0 and renderer.counters()["tile_parts"] == 0
         assert natural.tobytes() == first.tobytes()
     finally:
         renderer.set_tile_scheduling(True)
