@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W [--workload default|menger2|uhd|closeup6|synthetic]
                     [--evaluator lattice|exhaustive] [--kernel-mode compiled|interpreted]
 
-A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4; 8 on
-two or three GPUs, 16 from four on), each on its own stream, alternate frames: the timed region holds exactly
+A step is one frame of the workload.  Frames are independent, so --frames-in-flight contexts (default 4; 8 from
+eight GPUs on), each on its own stream, alternate frames: the timed region holds exactly
 K whole frames, all finished and gathered (streams drained) before the clock stops.  At N > 1 (one process per
 GPU, launched by torch.distributed.run) the frame's row bands are dealt cyclically to the ranks, every rank
 renders its bands into device memory and the RGBA8 bands are gathered to rank 0 with RCCL (the one exchange
@@ -44,8 +44,8 @@ sys.path.insert(0, ROOT)
 
 # Frames in flight run on one HIP stream each; HIP maps streams onto this many hardware queues per process
 # (its default, 4, would let only four frames overlap).  Read when the runtime starts, hence set before torch.
-# A sharded run keeps up to 16 frames in flight, and the collective's own stream must not share a queue with a
-# frame's: a gather waiting for its frame would hold up the frames queued behind it.
+# A sharded run keeps up to 8 frames in flight (16 tried), and the collective's own stream must not share a queue
+# with a frame's: a gather waiting for its frame would hold up the frames queued behind it.
 _QUEUES = 24 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--emulate-share" in sys.argv or "--force-collective" in sys.argv) else 8
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < _QUEUES:
     os.environ["GPU_MAX_HW_QUEUES"] = str(_QUEUES)
@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="contexts/streams per GPU that alternate frames (default: 4; 8 on two or three GPUs and 16 from four on, "
+                    help="contexts/streams per GPU that alternate frames (default: 4, and 8 from eight GPUs on, "
                          "where one rank's share of a frame is short against its longest-running tiles)")
     ap.add_argument("--frames-per-gather", type=int, default=0,
                     help="frames whose shards go to rank 0 in one collective (default 1)")
@@ -182,7 +182,7 @@ def main():
     # render of frame i + 1)
     # The smaller a rank's share, the more frames it takes to hide one frame's longest tiles.
     split = max(world, a.emulate_share)
-    F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split == 1 else 8 if split < 4 else 16)
+    F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split < 8 else 8)
     # frames per collective (one measured best on one GPU: queueing a gather costs the host ~0.03 ms, less than a
     # rank's share of a default frame takes to render at N = 8, and frames gathered together wait for each other)
     G = a.frames_per_gather if a.frames_per_gather > 0 else 1

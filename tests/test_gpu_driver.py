@@ -43,8 +43,8 @@ def test_driver_reports_a_missing_scene_like_the_reference(tmp_path):
     assert (img[..., :3] == 0).all() and (img[..., 3] == 255).all()
 
 
-@pytest.mark.parametrize("extra,batch", [([], []), (["--balance"], []), ([], ["--frames-per-gather", "4"])],
-                         ids=["cyclic", "dealt-by-cost", "four-frames-per-gather"])
+@pytest.mark.parametrize("extra,batch", [([], []), (["--balance"], []), ([], ["--frames-per-gather", "2"])],
+                         ids=["cyclic", "dealt-by-cost", "two-frames-per-gather"])
 def test_two_rank_bench_rehearsal_gathers_the_single_launch_frame(extra, batch):
     """bench.py's N > 1 path (cyclic bands, frames in flight, gather to rank 0, assembly) with both ranks on this
     one GPU and gloo in place of RCCL: the gathered frames must equal the frame a single launch renders."""
@@ -58,5 +58,5 @@ def test_two_rank_bench_rehearsal_gathers_the_single_launch_frame(extra, batch):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["gathered_frame_equals_single_launch"] is True
-    assert line["value"] > 0 and line["config"]["frames_in_flight"] == 8 and line["config"]["frames_per_gather"] == (4 if batch else 1)
+    assert line["value"] > 0 and line["config"]["frames_in_flight"] == 4 and line["config"]["frames_per_gather"] == (2 if batch else 1)
     assert ("dealt by measured cost" in line["config"]["sharding"]) == bool(extra)
