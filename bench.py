@@ -71,8 +71,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS))
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
