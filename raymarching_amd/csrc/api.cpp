@@ -125,8 +125,7 @@ namespace {
 // sample would double the divergent lattice walks.  128 registers per lane (4 waves per SIMD)
 // avoid all spills.
 constexpr int kCompiledPts = 1, kCompiledWaves = 4;
-constexpr size_t kSplitShare = 64;   // at most one tile in this many is split (counted in quarter splits)
-constexpr double kQuartersFrom = 0.6, kSixteenthsFrom = 0.8;   // shares of the longest tile's duration
+constexpr size_t kSixteenthTiles = 16, kQuarterTiles = 32;   // how many of the longest tiles are launched in 16 and in 4 parts
 
 int check_ready(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
@@ -190,7 +189,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->measured_tiles_y = (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
             pend.splittable = compiled && ctx->module.waves_per_group == 1u && pts == 1u;
-            RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 4u * (pend.n_tiles / kSplitShare + 4u)));
+            RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
             fr.tile_cost = ctx->d_tile_cost.ptr;
         }
     }
@@ -232,28 +231,28 @@ int finish_bands(rm_context *ctx) {
         RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, pend.n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-        // The frame cannot end before its longest tile does.  Tiles that ran nearly as long as the longest (a handful,
-        // where a few rays take hundreds of expensive steps) are listed as 4 or 16 workgroups, each of which waits only
-        // for its own samples: measured on the shipped frame, 0.86 -> 0.62 ms alone on the GPU with these thresholds;
-        // lower ones split more tiles than the shorter tail pays for.
+        // The frame cannot end before its longest tile does.  The tiles that ran longest -- a few dozen, where a few rays
+        // take hundreds of expensive steps -- are listed as 16 or 4 workgroups, each of which waits only for its own
+        // samples: measured on the shipped frame, 0.85 -> 0.62 ms alone on the GPU.  By rank, because the measured
+        // durations of the longest tiles vary by 10 % from run to run; splitting more tiles (64 into sixteenths, or 64
+        // more into quarters) costs more in extra waves than the shorter tail pays for.  A frame whose tiles all take
+        // about as long has no tail to shorten: only tiles far above the median, and not far below the longest.
         std::vector<uint32_t> entries;
-        entries.reserve(order.size() + 4u * (order.size() / kSplitShare + 4u));
-        size_t n_split = 0;
+        entries.reserve(order.size() + 15u * kSixteenthTiles + 3u * kQuarterTiles);
         const double longest = order.empty() ? 0.0 : (double)cost[order[0]];
-        const size_t most = order.size() / kSplitShare;   // in units of quarter splits
         const uint32_t median = order.empty() ? 0u : cost[order[order.size() / 2]];
+        size_t rank = 0;
         for (uint32_t t : order) {
-            // (a frame of tiles that all take about as long has no tail to shorten: only tiles far above the median)
-            const bool may = pend.splittable && cost[t] > 8u * median && t <= rmdev::kTileMask;
-            if (may && n_split + 4 <= most && (double)cost[t] >= kSixteenthsFrom * longest) {
+            const bool may = pend.splittable && rank < kSixteenthTiles + kQuarterTiles && cost[t] > 8u * median &&
+                             (double)cost[t] >= 0.3 * longest && t <= rmdev::kTileMask;
+            if (may && rank < kSixteenthTiles) {
                 for (uint32_t q = 0; q < 16u; q++) entries.push_back(t | ((q + 5u) << rmdev::kTileBits));
-                n_split += 4;
-            } else if (may && n_split < most && (double)cost[t] >= kQuartersFrom * longest) {
+            } else if (may) {
                 for (uint32_t q = 0; q < 4u; q++) entries.push_back(t | ((q + 1u) << rmdev::kTileBits));
-                n_split++;
             } else {
                 entries.push_back(t);
             }
+            rank++;
         }
         RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, entries.data(), entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         ctx->order_extra = (uint32_t)(entries.size() - order.size());
