@@ -324,6 +324,29 @@ def main():
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
     if timed_kernel_ms:
         kernel_ms = overlapped_ms = sum(timed_kernel_ms) / len(timed_kernel_ms)   # one frame in flight: the timed frames themselves
+    # ---- the same frames with every sample and every ray doing the reference's full work (one GPU only; after the
+    # timed region): the rate at which the frame's nominal rays are all marched
+    all_marched = None
+    if world == 1 and not group and a.emulate_share <= 1 and a.shading == "coloured":
+        for rr, sh in zip(rs, shards):
+            rr.set_shading(False)
+            for _ in range(3):                        # times the tiles of the new setting, then runs in cost order
+                rr.render_device(rows, None, sh.data_ptr())
+        n_all = max(F, min(a.steps, 100))
+        for i in range(F):
+            frame(i, i == F - 1)
+        drain()
+        t1 = time.perf_counter()
+        for i in range(n_all):
+            frame(i, i == n_all - 1)
+        drain()
+        all_ms = (time.perf_counter() - t1) / n_all * 1e3
+        all_marched = {"value": round(rays_per_frame / all_ms / 1e3, 3), "unit": "Mrays/s", "ms_per_step": round(all_ms, 4), "steps": n_all,
+                       "note": "rm_set_shading(RM_SHADE_ALL): no sample skips its normal and shadow rays, no shadow ray stops past its "
+                               "light; same frames, timed right after the main region in the same process"}
+        for rr in rs:
+            rr.set_shading(True)
+        timed_kernel_ms.clear()
     # ---- self-check of the sharded path (outside the timed region): the frames gathered on rank 0 must equal
     # the frame one launch renders
     gathered_ok = None
@@ -433,6 +456,7 @@ def main():
             "frame_ms": round(ms_per_step, 4),
             "host_issue_ms_per_frame": round(host_issue_ms, 4),
             "mrays_cast_per_s": round(total_rays * a.steps / elapsed / 1e6, 3),
+            "every_ray_marched": all_marched,
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }
         if exhaustive:
