@@ -110,6 +110,7 @@ struct rm_context {
     struct Pending {
         bool active = false, measuring = false, by_cost = false, compiled = false, counted = false;
         bool splittable = false;   // the kernel takes quarter-tile entries (one wave per workgroup, one sample per lane)
+        uint32_t part_multiple = 1;   // a part's side in samples must be a multiple of this (whole pixels when the kernel writes pixels)
         size_t n_tiles = 0;
     };
     Pending pending;
@@ -157,9 +158,18 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         fr.band_list = ctx->d_band_list.ptr;
     }
     fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
-    RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
     const bool compiled = ctx->module.loaded();
     const bool wide_runs = ctx->program.run_prims >= 64;
+    // Kernels of one wave per workgroup and one sample per lane write the pixels themselves when their 8 x 8-sample
+    // tiles hold whole pixels; otherwise the trace kernel writes samples and the resolve kernel adds them up.
+    const bool fused = compiled && ctx->module.waves_per_group == 1u && kCompiledPts == 1 && fr.kernel <= 8u && 8u % fr.kernel == 0u &&
+                       (d_f32 || d_rgba8);
+    if (fused) {
+        fr.pixels_f32 = d_f32;
+        fr.pixels_rgba8 = d_rgba8;
+    } else {
+        RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
+    }
     rm_context::Pending &pend = ctx->pending;
     pend = rm_context::Pending{};
     pend.compiled = compiled;
@@ -189,6 +199,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->measured_tiles_y = (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
             pend.splittable = compiled && ctx->module.waves_per_group == 1u && pts == 1u;
+            pend.part_multiple = fused ? fr.kernel : 1u;
             RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
             fr.tile_cost = ctx->d_tile_cost.ptr;
         }
@@ -210,7 +221,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
+    if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     pend.active = true;
     return RM_OK;
@@ -245,9 +256,9 @@ int finish_bands(rm_context *ctx) {
         for (uint32_t t : order) {
             const bool may = pend.splittable && rank < kSixteenthTiles + kQuarterTiles && cost[t] > 8u * median &&
                              (double)cost[t] >= 0.3 * longest && t <= rmdev::kTileMask;
-            if (may && rank < kSixteenthTiles) {
+            if (may && rank < kSixteenthTiles && 2u % pend.part_multiple == 0u) {
                 for (uint32_t q = 0; q < 16u; q++) entries.push_back(t | ((q + 5u) << rmdev::kTileBits));
-            } else if (may) {
+            } else if (may && 4u % pend.part_multiple == 0u) {
                 for (uint32_t q = 0; q < 4u; q++) entries.push_back(t | ((q + 1u) << rmdev::kTileBits));
             } else {
                 entries.push_back(t);

@@ -113,6 +113,28 @@ __device__ __forceinline__ bool value_can_change(float acc, float v) {
     return MAX ? !(c <= acc) : !(c >= acc);
 }
 
+// render.cpp:113-119 and the image writer's rule: pixel = total / (k * k), alpha 1; RGBA8 = round(clamp(c, 0, 1) * 255).
+// (x, y): pixel in the launch's compact band image of `width` pixels per row.
+__device__ __forceinline__ void store_pixel(float tx, float ty, float tz, uint32_t k, uint32_t width, uint32_t x, uint32_t y,
+                                            float *__restrict__ out_f32, unsigned char *__restrict__ out_rgba8) {
+    const float n = (float)(k * k);
+    const float r = tx / n, g = ty / n, b = tz / n;
+    const size_t o = ((size_t)y * width + x) * 4;
+    if (out_f32) {
+        typedef float Out4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<Out4 *>(out_f32 + o) = Out4{ r, g, b, 1.0f };
+    }
+    if (out_rgba8) {
+        const float cr = __builtin_fminf(__builtin_fmaxf(0.0f, r), 1.0f);
+        const float cg = __builtin_fminf(__builtin_fmaxf(0.0f, g), 1.0f);
+        const float cb = __builtin_fminf(__builtin_fmaxf(0.0f, b), 1.0f);
+        const uint32_t qr = (uint32_t)(int)(cr * 255.0f + 0.5f);
+        const uint32_t qg = (uint32_t)(int)(cg * 255.0f + 0.5f);
+        const uint32_t qb = (uint32_t)(int)(cb * 255.0f + 0.5f);
+        *reinterpret_cast<uint32_t *>(out_rgba8 + o) = qr | (qg << 8) | (qb << 16) | (255u << 24);
+    }
+}
+
 // Marks a branch whose body must stay in the branch (stops the compiler from turning a cheap-looking
 // body into unconditional code with selects).
 __device__ __forceinline__ void keep_in_branch() { asm volatile(""); }

@@ -155,6 +155,11 @@ struct FrameView {
     // Which image band each band of the launch is (null: band b is first_band + b * band_stride): lets
     // a caller deal bands to GPUs by measured cost instead of cyclically.
     const uint32_t *band_list;
+    // Pixels straight from the trace kernel (either pointer may be null; both null: the kernel writes `samples` for
+    // the resolve kernel instead).  Set only for kernels of one wave per workgroup and one sample per lane, and only
+    // when the SSAA kernel divides the tile's 8 samples per side, so that a workgroup holds whole pixels.
+    float *pixels_f32;
+    unsigned char *pixels_rgba8;
     // Nonzero: samples whose surface has no colour skip the normal and the shadow rays (their product with
     // the lighting is zero either way) and shadow rays stop once past their light; zero: every sample and
     // ray does the reference's full work, which is what work counts that are compared with the reference's need.

@@ -64,21 +64,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
             tz += s.z;
         }
     }
-    const float n = (float)(k * k);
-    const float r = tx / n, g = ty / n, b = tz / n;
-    const size_t o = ((size_t)y * fr.width + x) * 4;
-    if (out_f32) {
-        *reinterpret_cast<float4 *>(out_f32 + o) = make_float4(r, g, b, 1.0f);
-    }
-    if (out_rgba8) {
-        const float cr = __builtin_fminf(__builtin_fmaxf(0.0f, r), 1.0f);
-        const float cg = __builtin_fminf(__builtin_fmaxf(0.0f, g), 1.0f);
-        const float cb = __builtin_fminf(__builtin_fmaxf(0.0f, b), 1.0f);
-        const uint32_t qr = (uint32_t)(int)(cr * 255.0f + 0.5f);
-        const uint32_t qg = (uint32_t)(int)(cg * 255.0f + 0.5f);
-        const uint32_t qb = (uint32_t)(int)(cb * 255.0f + 0.5f);
-        *reinterpret_cast<uint32_t *>(out_rgba8 + o) = qr | (qg << 8) | (qb << 16) | (255u << 24);
-    }
+    store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
 }
 
 }  // namespace

@@ -257,9 +257,13 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         }
     }
 
+    // Whole pixels in the workgroup (see FrameView::pixels_f32): the samples meet in LDS and the lane of every
+    // pixel's first sample adds them up in the reference's order (render.cpp:103-112: i, the column, outer; j inner).
+    const bool fused = kWaves == 1 && kPts == 1 && (fr.pixels_f32 || fr.pixels_rgba8);
+    __shared__ float tile_rgb[kWaves == 1 && kPts == 1 ? 3 * 64 : 1];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
-        if (!stored[s]) continue;
+        if (!stored[s] && !fused) continue;
         V3 color = v3(0.0f, 0.0f, 0.0f);
         if (live[s]) {
             const float light = __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f);
@@ -270,7 +274,29 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             }
             color = v3(light * base.x, light * base.y, light * base.z);
         }
-        samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
+        if (kWaves == 1 && kPts == 1 && fused) {
+            if (in_part) {
+                float *mine = tile_rgb + 3u * (row * 8u + col);
+                mine[0] = color.x;
+                mine[1] = color.y;
+                mine[2] = color.z;
+            }
+            __syncthreads();
+            if (stored[s] && sx0 % k == 0u && sy % k == 0u) {
+                float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+                for (uint32_t i = 0; i < k; ++i) {
+                    for (uint32_t j = 0; j < k; ++j) {
+                        const float *c = tile_rgb + 3u * ((row + j) * 8u + col + i);
+                        tx += c[0];
+                        ty += c[1];
+                        tz += c[2];
+                    }
+                }
+                store_pixel(tx, ty, tz, k, fr.width, sx0 / k, sy / k, fr.pixels_f32, fr.pixels_rgba8);
+            }
+        } else {
+            samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
+        }
     }
 
     if (fr.tile_cost) {

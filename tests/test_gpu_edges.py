@@ -30,7 +30,8 @@ def test_twenty_lights(rm, oracle, renderer):
     assert gpu.tobytes() == cpu.tobytes()
 
 
-@pytest.mark.parametrize("kw", [dict(width=40, height=30, kernel=5), dict(width=1, height=1, kernel=3), dict(width=257, height=1, kernel=2),
+@pytest.mark.parametrize("kw", [dict(width=40, height=30, kernel=5), dict(width=45, height=31, kernel=4), dict(width=21, height=13, kernel=8),
+                                dict(width=3, height=2, kernel=4), dict(width=1, height=1, kernel=3), dict(width=257, height=1, kernel=2),
                                 dict(width=3, height=129, kernel=1), dict(width=64, height=48, kernel=2, iterations=7),
                                 dict(width=64, height=48, kernel=1, iterations=1), dict(width=48, height=32, kernel=2, iterations=0),
                                 dict(width=64, height=48, kernel=2, surface_eps=0.05, offset_eps=0.2),

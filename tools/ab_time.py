@@ -14,6 +14,9 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--scene", default="default")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--exhaustive", action="store_true")
+ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--height", type=int, default=0)
+ap.add_argument("--kernel", type=int, default=0, help="SSAA kernel (with --width/--height: another frame size of the scene)")
 ap.add_argument("--in-flight", type=int, default=0, help="also time the frame rate with this many contexts alternating frames")
 a = ap.parse_args()
 
@@ -24,6 +27,10 @@ for path in a.libs:
     L = binding.lib()
     r = binding.Renderer(0)
     kw = dict(kernel=1) if a.scene == "menger2" else {}
+    if a.width:
+        kw.update(width=a.width, height=a.height)
+    if a.kernel:
+        kw.update(kernel=a.kernel)
     r.set_params(binding.default_params(**kw))
     r.set_evaluator(not a.exhaustive)
     r.set_scene(binding.Scene(os.path.join(ROOT, "scenes", a.scene + ".txt")))
