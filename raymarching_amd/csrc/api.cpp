@@ -79,7 +79,8 @@ struct rm_context {
     rmdev::SceneView scene{};
 
     DeviceArray<rmdev::Rec> d_recs;
-    DeviceArray<rmdev::Float4> d_pa, d_pb, d_colors, d_lights, d_samples;
+    DeviceArray<rmdev::Float4> d_pa, d_pb, d_colors, d_lights;
+    DeviceArray<rmdev::Sample> d_samples;
     DeviceArray<float> d_frame_f32;
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
@@ -221,7 +222,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, ctx->d_samples.ptr, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
+    if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     pend.active = true;
     return RM_OK;

@@ -303,7 +303,7 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
     char buf[512];
     std::snprintf(buf, sizeof buf,
-                  "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(const SceneView sc, const FrameView fr, Float4 *samples,\n"
+                  "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
                   "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s, %d>(sc, fr, samples, counters);\n}\n\n",
                   64 * waves_per_group, min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane,
                   counting ? "true" : "false", waves_per_group);

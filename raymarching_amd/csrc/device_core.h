@@ -113,6 +113,17 @@ __device__ __forceinline__ bool value_can_change(float acc, float v) {
     return MAX ? !(c <= acc) : !(c >= acc);
 }
 
+// scene::raymarch's result for one sample (scene.cpp:31): light * colour of the surface's primitive; no surface,
+// or a sample outside the image: (0, 0, 0).
+__device__ __forceinline__ V3 sample_colour(const Float4 *__restrict__ colors, Sample s) {
+    V3 base = v3(0.0f, 0.0f, 0.0f);
+    if (s.prim != kNoPrim) {
+        const Float4 c = colors[s.prim];
+        base = v3(c.x, c.y, c.z);
+    }
+    return v3(s.light * base.x, s.light * base.y, s.light * base.z);
+}
+
 // render.cpp:113-119 and the image writer's rule: pixel = total / (k * k), alpha 1; RGBA8 = round(clamp(c, 0, 1) * 255).
 // (x, y): pixel in the launch's compact band image of `width` pixels per row.
 __device__ __forceinline__ void store_pixel(float tx, float ty, float tz, uint32_t k, uint32_t width, uint32_t x, uint32_t y,

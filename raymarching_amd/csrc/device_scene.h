@@ -78,6 +78,11 @@ struct Rec {
 //   row_prim[i] = depth-first index of the primitive (colour row, tie-break rank)
 struct Float4 { float x, y, z, w; };
 
+// One SSAA sample as the trace kernel leaves it for the resolve kernel: scene::raymarch's result is
+// light * colour of the surface's primitive (scene.cpp:31); the product is formed where the samples are added up,
+// so a sample is 8 bytes instead of 16.  prim = kNoPrim: no surface (colour 0, 0, 0).
+struct Sample { float light; uint32_t prim; };
+
 // ---- Menger lattice tables -------------------------------------------------
 // A run of cubic crosses is a "complete Menger lattice of n levels" when cross m (in the
 // generator's depth-first order, body.cpp:114-147) sits at (X_l[ix], Y_l[iy], Z_l[iz]) with

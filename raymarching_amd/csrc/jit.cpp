@@ -185,7 +185,7 @@ uint32_t lds_bytes_of(const SceneView &sc) { return (sc.lattice_words + sc.max_d
 
 }  // namespace
 
-hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
+hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Sample *samples,
                                WorkCounters *counters, hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;

@@ -41,7 +41,7 @@ void set_kernel_cache_dir(const char *dir);
 // The compile step alone (no device needed): true if `source` compiles for gfx950.
 bool check_scene_source(const std::string &source, std::string &log);
 
-hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Float4 *samples,
+hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Sample *samples,
                                WorkCounters *counters, hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                                   uint32_t *prim, float *sd_march, hipStream_t stream);

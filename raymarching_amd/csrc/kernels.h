@@ -15,12 +15,12 @@ size_t sample_texels(const FrameView &fr);
 // normal, one shadow ray per light, shading) into `samples`.
 // counters may be null (no counting).  wide_runs selects the one-sample-per-lane variant, for
 // scenes whose cost lies in long primitive runs.
-hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Float4 *samples,
+hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Sample *samples,
                         WorkCounters *counters, hipStream_t stream);
 
 // Averages the kernel x kernel samples of each pixel in the reference's
 // accumulation order and writes float RGBA and/or RGBA8 (either may be null).
-hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out_f32,
+hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sample *samples, float *out_f32,
                           unsigned char *out_rgba8, hipStream_t stream);
 
 // Scene SDF with colour tracking at n points.

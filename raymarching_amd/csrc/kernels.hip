@@ -34,7 +34,7 @@ namespace {
 // kWaves: waves per workgroup (4: 16 x 16 lanes; 1: 8 x 8, finer scheduling for scenes whose tiles run long).
 template <int kPts, int MIN_WAVES, bool COUNT, int kWaves>
 __global__ __launch_bounds__(64 * kWaves, MIN_WAVES) void trace_kernel(const SceneView sc, const FrameView fr,
-                                                                       Float4 *__restrict__ samples,
+                                                                       Sample *__restrict__ samples,
                                                                        WorkCounters *__restrict__ counters) {
     trace_body<InterpretedScene, kPts, COUNT, kWaves>(sc, fr, samples, counters);
 }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const
 
 // render.cpp:103-119: total += colour over i (outer, x) then j (inner, y);
 // pixel = total / (k*k), alpha 1.  RGBA8 = round(clamp(c, 0, 1) * 255).
-__global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const Float4 *__restrict__ samples,
+__global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const Float4 *__restrict__ colors, const Sample *__restrict__ samples,
                                                        float *__restrict__ out_f32, unsigned char *__restrict__ out_rgba8) {
     const uint32_t rows = fr.band_count * fr.band_rows;
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;
     for (uint32_t i = 0; i < k; ++i) {
         for (uint32_t j = 0; j < k; ++j) {
-            const Float4 s = samples[((size_t)y * k + j) * sw + (size_t)x * k + i];
-            tx += s.x;
-            ty += s.y;
-            tz += s.z;
+            const V3 c = sample_colour(colors, samples[((size_t)y * k + j) * sw + (size_t)x * k + i]);
+            tx += c.x;
+            ty += c.y;
+            tz += c.z;
         }
     }
     store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
@@ -73,7 +73,7 @@ size_t sample_texels(const FrameView &fr) {
     return (size_t)fr.band_count * fr.band_rows * fr.kernel * (size_t)fr.width * fr.kernel;
 }
 
-hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Float4 *samples, WorkCounters *counters,
+hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs, Sample *samples, WorkCounters *counters,
                         hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
@@ -91,12 +91,12 @@ hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(const FrameView &fr, const Float4 *samples, float *out_f32, unsigned char *out_rgba8,
+hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sample *samples, float *out_f32, unsigned char *out_rgba8,
                           hipStream_t stream) {
     const uint32_t rows = fr.band_count * fr.band_rows;
     if (fr.width == 0 || rows == 0) return hipSuccess;
     const dim3 grid((fr.width + 63u) / 64u, (rows + 3u) / 4u, 1u);
-    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, fr, samples, out_f32, out_rgba8);
+    hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, fr, colors, samples, out_f32, out_rgba8);
     return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 // primitive runs (vector-ALU bound), where idling would cost more than the scalar unit saves.
 // MIN_WAVES: waves per SIMD the register allocation must allow.
 template <class Scene, int kPts, bool COUNT, int kWaves = 4>
-__device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Float4 *__restrict__ samples,
+__device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
     __shared__ unsigned long long block_counts[6];
     if (COUNT) {
@@ -264,17 +264,11 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
         if (!stored[s] && !fused) continue;
-        V3 color = v3(0.0f, 0.0f, 0.0f);
-        if (live[s]) {
-            const float light = __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f);
-            V3 base = v3(0.0f, 0.0f, 0.0f);
-            if (prim[s] != kNoPrim) {
-                const Float4 c = sc.colors[prim[s]];
-                base = v3(c.x, c.y, c.z);
-            }
-            color = v3(light * base.x, light * base.y, light * base.z);
-        }
+        // scene::lighting's clamp (scene.cpp:60); the product with the colour is formed where the samples are added up
+        Sample sample_out = { 0.0f, kNoPrim };
+        if (live[s]) sample_out = Sample{ __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f), prim[s] };
         if (kWaves == 1 && kPts == 1 && fused) {
+            const V3 color = sample_colour(sc.colors, sample_out);
             if (in_part) {
                 float *mine = tile_rgb + 3u * (row * 8u + col);
                 mine[0] = color.x;
@@ -295,7 +289,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 store_pixel(tx, ty, tz, k, fr.width, sx0 / k, sy / k, fr.pixels_f32, fr.pixels_rgba8);
             }
         } else {
-            samples[(size_t)sy * sw + sx0 + (uint32_t)s] = Float4{ color.x, color.y, color.z, 0.0f };
+            samples[(size_t)sy * sw + sx0 + (uint32_t)s] = sample_out;
         }
     }
 
