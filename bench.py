@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--shading", choices=["coloured", "all"], default="coloured",
                     help="coloured (the library's default): samples on surfaces of colour (0, 0, 0) skip the normal and the "
                          "shadow rays, whose product with that colour is zero; all: every sample does the reference's full work")
+    ap.add_argument("--no-every-ray-leg", action="store_true",
+                    help="skip the extra timing of the same frames with the shading cuts off (keeps a kernel profile of the run to the main setting's launches)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: still form the RCCL group and send every frame through the gather and the "
                          "assembly (exercises the N > 1 code path's RCCL calls on a single GPU)")
@@ -327,7 +329,7 @@ def main():
     # ---- the same frames with every sample and every ray doing the reference's full work (one GPU only; after the
     # timed region): the rate at which the frame's nominal rays are all marched
     all_marched = None
-    if world == 1 and not group and a.emulate_share <= 1 and a.shading == "coloured":
+    if world == 1 and not group and a.emulate_share <= 1 and a.shading == "coloured" and not a.no_every_ray_leg:
         for rr, sh in zip(rs, shards):
             rr.set_shading(False)
             for _ in range(3):                        # times the tiles of the new setting, then runs in cost order

@@ -15,8 +15,8 @@ cd /tmp
 export TMPDIR=/tmp
 # one frame in flight here, so that every rm_trace launch runs alone and the statistics' average duration is
 # the kernel's own (with several frames in flight the spans of co-scheduled kernels stretch)
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o default --output-format csv -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --frames-in-flight 1 --no-cpu-baseline --no-exhaustive-leg > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats_f4" -o default --output-format csv -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats_f4_bench.json" 2> "$OUT/stats_f4.err"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o default --output-format csv -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --frames-in-flight 1 --no-cpu-baseline --no-exhaustive-leg --no-every-ray-leg > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats_f4" -o default --output-format csv -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-every-ray-leg > "$OUT/stats_f4_bench.json" 2> "$OUT/stats_f4.err"
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_fetch.log" 2>&1
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_write.log" 2>&1
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_sq1" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_sq1.log" 2>&1
