@@ -7,7 +7,7 @@ roofline.traffic.
 
 HBM bytes per trace launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB).  FETCH_SIZE counts the
 128-byte requests of wide coalesced reads at 64 bytes on gfx950, hence the factor 2; WRITE_SIZE is exact for
-the 16-byte-per-lane stores this kernel issues."""
+the 8- and 16-byte-per-lane stores these kernels issue."""
 import argparse
 import csv
 import glob

@@ -22,4 +22,10 @@ timeout -s KILL 90 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write"
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_sq1" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_sq1.log" 2>&1
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_WAVES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA -d "$OUT/pmc_sq2" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_sq2.log" 2>&1
 python3 "$REPO/tools/collect_traffic.py" --fetch "$OUT/pmc_fetch" --write "$OUT/pmc_write" --sq "$OUT/pmc_sq1" --workload default --evaluator lattice --kernel-mode compiled --out "$OUT/traffic.json"
+for w in menger2 uhd; do
+    timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_fetch_$w.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_write_$w.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_sq1_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_sq1_$w.log" 2>&1
+    python3 "$REPO/tools/collect_traffic.py" --fetch "$OUT/pmc_fetch_$w" --write "$OUT/pmc_write_$w" --sq "$OUT/pmc_sq1_$w" --workload $w --evaluator lattice --kernel-mode compiled --out "$OUT/traffic.json"
+done
 echo done
