@@ -92,7 +92,8 @@ typedef struct rm_counters {
     uint64_t flops_per_sdf;/* algorithmic FLOPs of one exhaustive scene SDF call:
                               11 per sphere, 9 per box, 15 per cross                  */
     double   kernel_ms;    /* device time of the trace kernel(s), HIP events        */
-    double   resolve_ms;   /* device time of the resolve kernel                     */
+    double   resolve_ms;   /* device time of the resolve kernel (0 where the trace kernel writes
+                              the pixels itself: compiled kernels, SSAA kernel 1, 2, 4 or 8) */
     double   compile_ms;   /* time rm_set_scene spent compiling the scene's kernels
                               (0: interpreted mode, or code object found in the cache) */
     uint32_t compiled_kernel; /* 1 if the last render ran the scene's own kernel      */
