@@ -641,6 +641,18 @@ void rmo_render(const rmo_scene *s, const rmo_params *p, uint32_t row0, uint32_t
     if (counters) *counters = total;
 }
 
+/* The same pixels, any subset of them: render::pixel (render.cpp:82-120) at n given (x, y) coordinates,
+ * dealt to the threads one at a time (tests check sparse rows of large frames with it; pixels are
+ * independent, so the split does not change a bit of any of them).  out: n x RGBA. */
+void rmo_render_pixels(const rmo_scene *s, const rmo_params *p, const uint32_t *xy, uint32_t n, int threads, float *out) {
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int i = 0; i < (int)n; i++)
+        render_pixel(s, p, (int)xy[2 * i], (int)xy[2 * i + 1], out + 4 * (size_t)i, NULL);
+}
+
 void rmo_pixel_samples(const rmo_scene *s, const rmo_params *p, uint32_t px, uint32_t py, float *rgb_out) {
     render_pixel(s, p, (int)px, (int)py, NULL, rgb_out);
 }

@@ -100,6 +100,11 @@ void        rmo_render(const rmo_scene *s, const rmo_params *p,
                        uint32_t row0, uint32_t row1, uint32_t row_step,
                        int threads, float *out, rmo_counters *counters);
 
+/* render::pixel at n arbitrary pixels, xy = (x, y) pairs, dealt to `threads` OpenMP threads;
+ * out = n x RGBA floats in list order. */
+void        rmo_render_pixels(const rmo_scene *s, const rmo_params *p, const uint32_t *xy,
+                              uint32_t n, int threads, float *out);
+
 /* One pixel's k*k sample colours in loop order (i outer, j inner): rgb*k*k. */
 void        rmo_pixel_samples(const rmo_scene *s, const rmo_params *p,
                               uint32_t px, uint32_t py, float *rgb_out);

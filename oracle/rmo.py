@@ -72,6 +72,7 @@ def lib():
         L.rmo_sdf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rmo_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_int, C.c_void_p, C.POINTER(Counters)]
+        L.rmo_render_pixels.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.rmo_pixel_samples.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_void_p]
         L.rmo_quantize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.rmo_default_params.argtypes = [C.POINTER(Params)]
@@ -168,6 +169,13 @@ class Scene:
         cnt = Counters()
         lib().rmo_render(self._h, C.byref(params), r0, r1, st, threads, out.ctypes.data, C.byref(cnt))
         return out, cnt.as_dict()
+
+    def render_pixels(self, params, xy, threads=0):
+        """RGBA floats of the pixels xy = [(x, y), ...] (any subset of the frame), rendered in parallel."""
+        xy = np.ascontiguousarray(xy, np.uint32).reshape(-1, 2)
+        out = np.zeros((len(xy), 4), np.float32)
+        lib().rmo_render_pixels(self._h, C.byref(params), xy.ctypes.data, len(xy), threads or lib().rmo_max_threads(), out.ctypes.data)
+        return out
 
     def pixel_samples(self, params, px, py):
         k = params.kernel

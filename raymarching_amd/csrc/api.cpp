@@ -94,6 +94,7 @@ struct rm_context {
         rm_rows rows;
         uint64_t scene_serial, band_list_serial;
         uint32_t points_per_lane, shading;
+        uint32_t fused;   // the trace kernel writes pixels itself: its tile parts must hold whole pixels
     };
     int tile_scheduling = RM_TILES_BY_COST;
     int shading = RM_SHADE_COLOURED;
@@ -188,6 +189,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.band_list_serial = ctx->band_list_size ? ctx->band_list_serial : 0;
         key.points_per_lane = pts;
         key.shading = (uint32_t)ctx->shading;
+        key.fused = fused ? 1u : 0u;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
             fr.extra_slots = ctx->order_extra;
