@@ -164,6 +164,27 @@ int rm_enqueue_device(rm_context *ctx, const rm_rows *rows, float *device_f32, u
 int rm_wait(rm_context *ctx);
 int rm_set_stream(rm_context *ctx, void *hip_stream);
 
+/*
+ * rm_enqueue_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The call itself allocates nothing
+ * (no hipMalloc / hipFree, no allocating library routine): what the kernels need beyond the caller's buffers --
+ * the SSAA sample image that the trace kernel leaves for the resolve kernel, 8 bytes per sample, wherever the
+ * trace kernel does not write the pixels itself -- lives in a static device array of RM_STATIC_SCRATCH_BYTES
+ * that every GPU the library runs on holds from the first rm_create on it until the process ends.
+ *   - A render whose sample image (band_count * band_rows * kernel rows of width * kernel samples) exceeds
+ *     the array is refused with RM_ERR_INVALID; render fewer rows per call.
+ *   - Tiles run in the order an earlier rm_render_device of the same configuration measured, if this context
+ *     holds one, in row-major order otherwise; this call never times tiles.  With work counting on it is
+ *     refused (RM_ERR_STATE).
+ *   - All contexts on a GPU share that GPU's array: calls that overlap on one GPU (two contexts on two
+ *     streams) race; queue them on one stream.  Nothing in it needs to start at zero: every call overwrites
+ *     the part it reads.
+ * Pair with rm_wait like rm_enqueue_device.  Same frame as rm_render_device, bit for bit.
+ */
+#define RM_STATIC_SCRATCH_BYTES (64u << 20)
+int rm_enqueue_device_static(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8);
+size_t rm_static_scratch_bytes(void);
+
 /* Scene SDF at n host points (xyz interleaved): signed distance and the index
  * (depth-first primitive order) of the primitive whose colour wins.  Exposes
  * the device evaluator of Body::List::SDF (body.cpp:66-111) for parity tests. */

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_set_band_list", "rm_enqueue_device", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -77,6 +77,8 @@ def lib():
     L.rm_render_f32.argtypes = [vp, vp]
     L.rm_render_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
     L.rm_enqueue_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_enqueue_device_static.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_static_scratch_bytes.restype = C.c_size_t
     L.rm_wait.argtypes = [vp]
     L.rm_set_band_list.argtypes = [vp, vp, C.c_uint32]
     L.rm_set_stream.argtypes = [vp, vp]
@@ -238,6 +240,10 @@ class Renderer:
     def enqueue_device(self, rows, f32_ptr=None, rgba8_ptr=None):
         """render_device without waiting; pair with wait()."""
         _check(lib().rm_enqueue_device(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_enqueue_device")
+
+    def enqueue_device_static(self, rows, f32_ptr=None, rgba8_ptr=None):
+        """enqueue_device through the library's static scratch: the call allocates nothing."""
+        _check(lib().rm_enqueue_device_static(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_enqueue_device_static")
 
     def set_band_list(self, image_bands):
         """image_bands: sequence of image band indices this context renders (None or empty: arithmetic bands)."""

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,6 +22,9 @@
 #include "kernels.h"
 #include "program.h"
 #include "scene.h"
+
+// The static scratch of rm_enqueue_device_static (see find_static_scratch below).
+static __device__ __align__(256) unsigned char scratch[RM_STATIC_SCRATCH_BYTES];
 
 namespace {
 
@@ -61,6 +65,34 @@ struct DeviceArray {
         capacity = 0;
     }
 };
+
+// ---- the static scratch of rm_enqueue_device_static ---------------------------------------------
+// Device memory the kernels need beyond the caller's inputs and outputs (the SSAA sample image that the trace
+// kernel leaves for the resolve kernel), held in the code object instead of allocated: every GPU this library
+// runs on carries its own copy of the array, at its own address, until the process ends.  `scratch` names
+// the array on the host side only; the address the kernels get is the one hipGetSymbolAddress reports for
+// the current device, looked up once per device in rm_create.
+constexpr size_t kStaticScratchBytes = RM_STATIC_SCRATCH_BYTES;
+constexpr int kMaxDevices = 64;
+void *g_scratch_of_device[kMaxDevices] = {};
+std::mutex g_scratch_lock;
+
+// with `device` current
+hipError_t find_static_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipSuccess;   // such a device renders through allocated buffers only
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_of_device[device]) return hipSuccess;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) g_scratch_of_device[device] = ptr;
+    return e;
+}
+
+void *static_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    return g_scratch_of_device[device];
+}
 
 }  // namespace
 
@@ -149,7 +181,10 @@ rmdev::FrameView frame_view(const rm_params &p, const rm_rows &rows) {
 // Trace + resolve of the given bands into device buffers; synchronises the stream.
 // Puts trace + resolve of the given bands on the context's stream.  may_measure: this frame may run in
 // natural tile order with every tile timed (its caller will call finish_bands before the next frame).
-int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure) {
+// static_samples: the device's static scratch (rm_enqueue_device_static) -- the call then allocates nothing: the sample
+// image goes there, tiles are never timed, and a configuration that would need a buffer the context does not hold is refused.
+int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure,
+                  rmdev::Sample *static_samples = nullptr) {
     if (rows.band_rows == 0 || rows.band_count == 0 || rows.band_stride == 0)
         return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
     RM_HIP(hipSetDevice(ctx->device));
@@ -169,9 +204,16 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     if (fused) {
         fr.pixels_f32 = d_f32;
         fr.pixels_rgba8 = d_rgba8;
+    } else if (static_samples) {
+        const size_t need = rmdev::sample_texels(fr) * sizeof(rmdev::Sample);
+        if (need > kStaticScratchBytes)
+            return fail(RM_ERR_INVALID, "rm_enqueue_device_static: this render needs " + std::to_string(need) + " bytes of scratch for its " +
+                                            std::to_string(rmdev::sample_texels(fr)) + " SSAA samples, the static buffer holds " +
+                                            std::to_string(kStaticScratchBytes) + " (render fewer rows per call, or use rm_enqueue_device)");
     } else {
         RM_HIP(ctx->d_samples.reserve(rmdev::sample_texels(fr)));
     }
+    rmdev::Sample *const samples = static_samples ? static_samples : ctx->d_samples.ptr;
     rm_context::Pending &pend = ctx->pending;
     pend = rm_context::Pending{};
     pend.compiled = compiled;
@@ -208,6 +250,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         }
     }
     rmdev::WorkCounters *d_cnt = nullptr;
+    if (ctx->counting && static_samples) return fail(RM_ERR_STATE, "rm_enqueue_device_static: work counting needs allocated buffers (rm_set_counting(ctx, 0) first)");
     if (ctx->counting) {
         RM_HIP(ctx->d_counters.reserve(1));
         d_cnt = ctx->d_counters.ptr;
@@ -221,10 +264,10 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, ctx->d_samples.ptr, d_cnt, ctx->stream));
-    else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, ctx->d_samples.ptr, d_cnt, ctx->stream));
+    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, samples, d_cnt, ctx->stream));
+    else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, samples, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, ctx->d_samples.ptr, d_f32, d_rgba8, ctx->stream));
+    if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, samples, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     pend.active = true;
     return RM_OK;
@@ -323,7 +366,8 @@ int rm_create(int device, rm_context **out) {
     rm_context *ctx = new (std::nothrow) rm_context();
     if (!ctx) return fail(RM_ERR_INVALID, "rm_create: out of host memory");
     ctx->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    hipError_t e = find_static_scratch(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
@@ -435,6 +479,16 @@ int rm_enqueue_device(rm_context *ctx, const rm_rows *rows, float *device_f32, u
     if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_device: null rows");
     return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false);
 }
+
+int rm_enqueue_device_static(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_device_static: null rows");
+    void *ptr = static_scratch(ctx->device);
+    if (!ptr) return fail(RM_ERR_STATE, "rm_enqueue_device_static: no static scratch on device " + std::to_string(ctx->device));
+    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false, static_cast<rmdev::Sample *>(ptr));
+}
+
+size_t rm_static_scratch_bytes(void) { return kStaticScratchBytes; }
 
 int rm_wait(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");

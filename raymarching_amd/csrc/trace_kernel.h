@@ -48,7 +48,12 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         float sd[kPts];
         Work work[kPts] = {};
         Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap);
-        if (COUNT) cnt.slots += kPts;
+        if (COUNT) {
+            // the wave sits through this iteration with all of its lanes, whichever of them still march (with one
+            // sample per lane the loop is left per lane): the first lane that is still here books the 64 slots
+            const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+            if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(here)) cnt.slots += 64u * kPts;
+        }
 #pragma unroll
         for (int s = 0; s < kPts; ++s) {
             if (!done[s]) {
