@@ -106,6 +106,11 @@ typedef struct rm_counters {
                               bound or a lattice are not counted), march steps excluded  */
     uint64_t tile_parts;   /* workgroups of the last render beyond one per tile: in cost order the few
                               tiles that run longest are launched as 4 or 16 parts           */
+    uint64_t probe[16];    /* diagnostic (counting renders of compiled kernels): lane occupancy of code regions as
+                              pairs (lanes that executed region r x weight, 64 x weight per wave that went through it):
+                              r = 0..3 lattice level 0, 1, 2, deeper (weight 1 per visit); 4 lattice row cells (weight =
+                              cells of the row); 5 gradient taps (lanes whose sample is shaded); 7 scene SDF calls of the
+                              march loop */
 } rm_counters;
 
 typedef struct rm_context rm_context;

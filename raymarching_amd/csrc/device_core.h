@@ -55,6 +55,28 @@ __host__ __device__ inline uint32_t lds_bytes(const SceneView &sc) {
     return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kMaxPts * 256u) * 4u;
 }
 
+// ---- occupancy probes (work-counting kernel variants only) ------------------------------------
+// Region r books, per wave that executes it, (lanes executing it) x weight into probe[2r] and 64 x weight into
+// probe[2r + 1]: their ratio is the region's lane utilisation, weight = the region's cost in instructions or cells.
+constexpr int kProbeLevel0 = 0, kProbeLevel1 = 1, kProbeLevel2 = 2, kProbeLevelDeep = 3, kProbeRowCells = 4, kProbeGradTap = 5,
+              kProbeColourPass = 6, kProbeSceneCall = 7;
+
+__device__ __forceinline__ unsigned long long *probe_words() {
+    __shared__ unsigned long long words[16];
+    return words;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void probe(int region, uint32_t weight) {
+    if (COUNT) {
+        const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(here)) {
+            atomicAdd(&probe_words()[2 * region], (unsigned long long)__builtin_popcountll(here) * weight);
+            atomicAdd(&probe_words()[2 * region + 1], 64ull * weight);
+        }
+    }
+}
+
 // ---- primitive distances (body.cpp:32-35, 41-45, 51-57) --------------------
 
 __device__ __forceinline__ float cross_value(float dx, float dy, float dz) {
@@ -462,11 +484,18 @@ __device__ __forceinline__ float *wave_slot() {
     return &slots[threadIdx.x >> 6];
 }
 
-template <int AXIS>
+template <int AXIS, bool COUNT = false>
 __device__ __forceinline__ float lattice_rows(bool active, const float *T, const uint32_t *ONES, int n, float pt, float h, float d1,
                                               float d2, uint32_t fixed_ones, float run) {
     const unsigned long long rows = __builtin_amdgcn_ballot_w64(active);
     if (rows == 0) return run;
+    if (COUNT) {
+        const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(here)) {
+            atomicAdd(&probe_words()[2 * kProbeRowCells], (unsigned long long)__builtin_popcountll(rows) * (uint32_t)n);
+            atomicAdd(&probe_words()[2 * kProbeRowCells + 1], 64ull * (uint32_t)n);
+        }
+    }
     if (n >= 27) {
         const unsigned long long workers = __builtin_amdgcn_ballot_w64(true);
         const int n_workers = __builtin_popcountll(workers), n_rows = __builtin_popcountll(rows);
@@ -606,14 +635,15 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     const float *X = (const float *)tab, *Y = X + N, *Z = Y + N;
     const uint32_t *ONES = tab + 3 * N;
     if (COUNT) n_evals += 3;
+    probe<COUNT>(N == 1 ? kProbeLevel0 : (N == 3 ? kProbeLevel1 : (N == 9 ? kProbeLevel2 : kProbeLevelDeep)), 1u);
     const int ix = nearest_index(p.x, x0, inv, N - 1), iy = nearest_index(p.y, y0, inv, N - 1), iz = nearest_index(p.z, z0, inv, N - 1);
     const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
     const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
     const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
     const bool rz = bx && by && !(ox & oy), ry = bx && bz && !(ox & oz), rx = by && bz && !(oy & oz);
-    run = lattice_rows<2>(rz, Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
-    run = lattice_rows<1>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
-    run = lattice_rows<0>(rx, X, ONES, N, p.x, h, dy, dz, oy | oz, run);
+    run = lattice_rows<2, COUNT>(rz, Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
+    run = lattice_rows<1, COUNT>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
+    run = lattice_rows<0, COUNT>(rx, X, ONES, N, p.x, h, dy, dz, oy | oz, run);
     if (COUNT) n_evals += (uint32_t)N * ((rz ? 1u : 0u) + (ry ? 1u : 0u) + (rx ? 1u : 0u));
     return kLatticeNext;
 }

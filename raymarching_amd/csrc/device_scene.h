@@ -178,6 +178,9 @@ struct WorkCounters {
     unsigned long long prim_evals;   // primitive distance evaluations (incl. lattice axis scans, 3 per level)
     unsigned long long flops;        // algorithmic FLOPs of the primitive evaluations executed (see Work)
     unsigned long long march_slots;  // march-loop iterations x samples of the lanes that sat through them (live or idle)
+    // Lane occupancy of code regions, as pairs (lanes that executed the region x its weight, 64 x weight per wave that
+    // went through it): see kProbe* in device_core.h.
+    unsigned long long probe[16];
 };
 
 }  // namespace rmdev

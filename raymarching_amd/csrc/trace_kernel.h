@@ -1,6 +1,6 @@
 // trace_kernel.h -- the render kernel body, generic over the scene evaluator `Scene`
 // (InterpretedScene, or the straight-line evaluator generated for one scene):
-//     Scene::sd<NP, COUNT>(sc, lds, points, distances, work)       distance only
+//     Scene::sd<NP, COUNT>(sc, lds, points, distances, work, cap)  distance only
 //     Scene::surface<NP>(sc, lds, points, distances, primitives)   distance + colour-carrying primitive
 #pragma once
 
@@ -48,6 +48,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         float sd[kPts];
         Work work[kPts] = {};
         Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap);
+        probe<COUNT>(kProbeSceneCall, 1u);
         if (COUNT) {
             // the wave sits through this iteration with all of its lanes, whichever of them still march (with one
             // sample per lane the loop is left per lane): the first lane that is still here books the 64 slots
@@ -86,6 +87,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     __shared__ unsigned long long block_counts[6];
     if (COUNT) {
         if (threadIdx.x < 6) block_counts[threadIdx.x] = 0;
+        if (threadIdx.x < 16) probe_words()[threadIdx.x] = 0;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t k = fr.kernel;
@@ -233,6 +235,16 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) no_cap[s] = __builtin_inff();
                     Scene::template sd<kPts, COUNT>(sc, lds, q, sd, work, no_cap);
+                    if (COUNT) {
+                        bool any_lit = false;
+#pragma unroll
+                        for (int s = 0; s < kPts; ++s) any_lit = any_lit || lit[s];
+                        const unsigned long long lit_lanes = __builtin_amdgcn_ballot_w64(any_lit);
+                        if ((threadIdx.x & 63u) == 0u) {
+                            atomicAdd(&probe_words()[2 * kProbeGradTap], (unsigned long long)__builtin_popcountll(lit_lanes));
+                            atomicAdd(&probe_words()[2 * kProbeGradTap + 1], 64ull);
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) {
                         if (COUNT && lit[s]) {
@@ -312,6 +324,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         atomicAdd(&block_counts[4], (unsigned long long)cnt.slots);
         atomicAdd(&block_counts[5], (unsigned long long)cnt.flops);
         __syncthreads();
+        if (threadIdx.x < 16 && probe_words()[threadIdx.x]) atomicAdd(&counters->probe[threadIdx.x], probe_words()[threadIdx.x]);
         if (threadIdx.x == 0) {
             atomicAdd(&counters->sdf_calls, block_counts[0]);
             atomicAdd(&counters->march_steps, block_counts[1]);
