@@ -127,6 +127,7 @@ struct rm_context {
         uint64_t scene_serial, band_list_serial;
         uint32_t points_per_lane, shading;
         uint32_t fused;   // the trace kernel writes pixels itself: its tile parts must hold whole pixels
+        uint32_t waves_per_side;   // tile shape of the launch
     };
     int tile_scheduling = RM_TILES_BY_COST;
     int shading = RM_SHADE_COLOURED;
@@ -143,8 +144,9 @@ struct rm_context {
     // the frame enqueued last and not yet booked by finish_bands
     struct Pending {
         bool active = false, measuring = false, by_cost = false, compiled = false, counted = false;
-        bool splittable = false;   // the kernel takes quarter-tile entries (one wave per workgroup, one sample per lane)
+        bool splittable = false;   // the kernel takes tile-part entries (one sample per lane)
         uint32_t part_multiple = 1;   // a part's side in samples must be a multiple of this (whole pixels when the kernel writes pixels)
+        uint32_t tile_side = 8;       // samples per tile side
         size_t n_tiles = 0;
     };
     Pending pending;
@@ -197,10 +199,25 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
     const bool compiled = ctx->module.loaded();
     const bool wide_runs = ctx->program.run_prims >= 64;
-    // Kernels of one wave per workgroup and one sample per lane write the pixels themselves when their 8 x 8-sample
-    // tiles hold whole pixels; otherwise the trace kernel writes samples and the resolve kernel adds them up.
-    const bool fused = compiled && ctx->module.waves_per_group == 1u && kCompiledPts == 1 && fr.kernel <= 8u && 8u % fr.kernel == 0u &&
-                       (d_f32 || d_rgba8);
+    // Launch shape.  Record walker: one wave of 8 x 8 samples per workgroup, or 2 x 2 waves with two samples per lane.
+    // Kernels generated for the scene: n x n waves per workgroup, n = 1 for the finest scheduling (a workgroup lasts as
+    // long as its slowest wave), 2 where large lattice tables are staged into LDS by every workgroup; they write the
+    // pixels themselves when a tile of 8n x 8n samples holds whole pixels, otherwise the trace kernel writes samples and
+    // the resolve kernel adds them up.  n = 3 would hold whole pixels for SSAA kernels 3, 6, 12 and 24 too, but nine-wave
+    // workgroups fill a CU's wave slots so unevenly that the shipped frame takes 0.82-0.99 ms instead of 0.58 with the
+    // resolve kernel (measured): that shape is used only where the sample image has nowhere to go (static scratch too small).
+    const bool large_tables = ctx->program.lattice.size() > 1024;
+    uint32_t n_side = compiled ? (large_tables ? 2u : 1u) : (wide_runs ? 1u : 2u);
+    bool fused = false;
+    if (compiled && (d_f32 || d_rgba8)) {
+        const uint32_t k = fr.kernel;
+        if ((8u * n_side) % k == 0u) {
+            fused = true;
+        } else if (static_samples && 24u % k == 0u && rmdev::sample_texels(fr) * sizeof(rmdev::Sample) > kStaticScratchBytes) {
+            n_side = 3u;
+            fused = true;
+        }
+    }
     if (fused) {
         fr.pixels_f32 = d_f32;
         fr.pixels_rgba8 = d_rgba8;
@@ -221,7 +238,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     // ---- tile schedule of this launch
     const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
-    const uint32_t side = (compiled ? ctx->module.waves_per_group == 1u : wide_runs) ? 8u : 16u;   // see launch_trace
+    const uint32_t side = 8u * n_side;
     pend.n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
     if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
         rm_context::OrderKey key{};
@@ -232,6 +249,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.points_per_lane = pts;
         key.shading = (uint32_t)ctx->shading;
         key.fused = fused ? 1u : 0u;
+        key.waves_per_side = n_side;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
             fr.extra_slots = ctx->order_extra;
@@ -243,8 +261,9 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->measured_tiles_x = (sw + side * pts - 1u) / (side * pts);
             ctx->measured_tiles_y = (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
-            pend.splittable = compiled && ctx->module.waves_per_group == 1u && pts == 1u;
+            pend.splittable = compiled && pts == 1u;
             pend.part_multiple = fused ? fr.kernel : 1u;
+            pend.tile_side = side;
             RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
             fr.tile_cost = ctx->d_tile_cost.ptr;
         }
@@ -259,12 +278,12 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     }
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, (int)ctx->module.waves_per_group, true),
-                                         kCompiledPts, ctx->module.waves_per_group, ctx->counting_module, log))
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
+                                         ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, samples, d_cnt, ctx->stream));
+    if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, n_side, samples, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, samples, d_cnt, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, samples, d_f32, d_rgba8, ctx->stream));
@@ -302,9 +321,9 @@ int finish_bands(rm_context *ctx) {
         for (uint32_t t : order) {
             const bool may = pend.splittable && rank < kSixteenthTiles + kQuarterTiles && cost[t] > 8u * median &&
                              (double)cost[t] >= 0.3 * longest && t <= rmdev::kTileMask;
-            if (may && rank < kSixteenthTiles && 2u % pend.part_multiple == 0u) {
+            if (may && rank < kSixteenthTiles && (pend.tile_side / 4u) % pend.part_multiple == 0u) {
                 for (uint32_t q = 0; q < 16u; q++) entries.push_back(t | ((q + 5u) << rmdev::kTileBits));
-            } else if (may && 4u % pend.part_multiple == 0u) {
+            } else if (may && (pend.tile_side / 2u) % pend.part_multiple == 0u) {
                 for (uint32_t q = 0; q < 4u; q++) entries.push_back(t | ((q + 1u) << rmdev::kTileBits));
             } else {
                 entries.push_back(t);
@@ -455,12 +474,9 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     ctx->module.unload();
     ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
-        // One wave per workgroup schedules finest (a workgroup lasts as long as its slowest wave), but every
-        // workgroup stages the lattice tables into LDS: large tables are shared by four waves instead.
-        const int group = ctx->program.lattice.size() > 1024 ? 4 : 1;
         std::string log;
-        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, group, false);
-        if (!rmdev::compile_scene_module(source, kCompiledPts, (uint32_t)group, ctx->module, log)) {
+        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false);
+        if (!rmdev::compile_scene_module(source, kCompiledPts, ctx->module, log)) {
             ctx->have_scene = false;
             return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
         }
@@ -567,7 +583,7 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
     std::string why;
     rmdev::HostProgram prog;
     if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_kernel_source: " + why);
-    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, prog.lattice.size() > 1024 ? 4 : 1, counting != 0);
+    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, counting != 0);
     *length = src.size();
     if (buffer && capacity) {
         const size_t n = src.size() < capacity - 1 ? src.size() : capacity - 1;

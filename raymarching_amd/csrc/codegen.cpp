@@ -290,7 +290,7 @@ std::string emit_body(const HostProgram &prog, bool track) {
 
 }  // namespace
 
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, int waves_per_group, bool counting) {
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting) {
     std::string s;
     s += "#include \"trace_kernel.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
@@ -301,12 +301,12 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
          "                                               float (&out_sd)[NP], uint32_t (&out_prim)[NP]) {\n";
     s += emit_body(prog, true);
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
+    // launched with 1, 4 or 9 waves per workgroup (jit.cpp: launch_trace_module)
     char buf[512];
     std::snprintf(buf, sizeof buf,
-                  "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
-                  "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s, %d>(sc, fr, samples, counters);\n}\n\n",
-                  64 * waves_per_group, min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane,
-                  counting ? "true" : "false", waves_per_group);
+                  "extern \"C\" __global__ __launch_bounds__(576, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
+                  "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s>(sc, fr, samples, counters);\n}\n\n",
+                  min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane, counting ? "true" : "false");
     s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
          "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n";

@@ -10,8 +10,8 @@
 namespace rmdev {
 
 // Kernels emitted: rm_trace (points_per_lane samples per lane, register budget for min_waves waves
-// per SIMD, workgroups of waves_per_group = 1 or 4 waves, with or without work counting) and
+// per SIMD, launched with 1, 4 or 9 waves per workgroup, with or without work counting) and
 // rm_eval_sdf; signatures as the kernels of kernels.hip.
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, int waves_per_group, bool counting);
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting);
 
 }  // namespace rmdev

@@ -36,13 +36,14 @@ __device__ __forceinline__ V3 normalize3(V3 a) {
     return a * inv;
 }
 
-// ---- LDS: lattice tables, then the parking area of nested lists -------------
+// ---- LDS: lattice tables, then the parking area of nested lists (record walker) or the tile's sample colours
+// (kernels generated for a scene, which keep nested lists in registers, when they write pixels themselves) -------
 
 extern __shared__ uint32_t lds_words[];
 
 struct Lds {
     const uint32_t *lattice;
-    uint32_t *park;   // [slot][sd | prim][point][thread]
+    uint32_t *park;   // record walker: [slot][sd | prim][point][thread]; generated kernels: [sample of the tile][rgb]
 };
 
 __device__ __forceinline__ Lds stage_lds(const SceneView &sc) {
@@ -51,6 +52,7 @@ __device__ __forceinline__ Lds stage_lds(const SceneView &sc) {
     return Lds{ lds_words, lds_words + sc.lattice_words };
 }
 
+// dynamic LDS of the record-walking kernels
 __host__ __device__ inline uint32_t lds_bytes(const SceneView &sc) {
     return (sc.lattice_words + sc.max_depth * 2u * (uint32_t)kMaxPts * 256u) * 4u;
 }
@@ -480,7 +482,7 @@ __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONE
 // evaluated which cell).  Must be called from control flow that is uniform among the executing
 // lanes; lanes that have left the walk earlier simply are not among the workers.
 __device__ __forceinline__ float *wave_slot() {
-    __shared__ float slots[4];
+    __shared__ float slots[16];   // workgroups have up to 9 waves
     return &slots[threadIdx.x >> 6];
 }
 

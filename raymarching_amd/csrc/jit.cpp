@@ -132,8 +132,7 @@ bool check_scene_source(const std::string &source, std::string &log) {
     return code != nullptr;
 }
 
-bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
-                          std::string &log) {
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
     out.unload();
     CodeObject code;
     {
@@ -174,18 +173,11 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, u
         }
     }
     out.points_per_lane = points_per_lane;
-    out.waves_per_group = waves_per_group;
     out.compile_seconds = seconds;
     return true;
 }
 
-namespace {
-
-uint32_t lds_bytes_of(const SceneView &sc) { return (sc.lattice_words + sc.max_depth * 2u * 2u * 256u) * 4u; }
-
-}  // namespace
-
-hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Sample *samples,
+hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
                                WorkCounters *counters, hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
@@ -194,11 +186,14 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
     SceneView sc_arg = sc;
     FrameView fr_arg = fr;
     void *args[] = { &sc_arg, &fr_arg, &samples, &counters };
-    const uint32_t side = m.waves_per_group == 4u ? 16u : 8u;
+    const uint32_t side = 8u * waves_per_side;
     const uint32_t tiles_x = (sw + side * pts - 1u) / (side * pts);
     const uint32_t extra_rows = fr.tile_order ? (fr.extra_slots + tiles_x - 1u) / tiles_x : 0u;
-    return hipModuleLaunchKernel(m.trace, tiles_x, (sh + side - 1u) / side + extra_rows, 1, 64u * m.waves_per_group, 1, 1,
-                                 lds_bytes_of(sc), stream, args, nullptr);
+    // generated kernels keep nested lists in registers: no parking area behind the lattice tables
+    const bool writes_pixels = fr.pixels_f32 || fr.pixels_rgba8;
+    const uint32_t lds = (sc.lattice_words + (writes_pixels ? 3u * side * side : 0u)) * 4u;
+    return hipModuleLaunchKernel(m.trace, tiles_x, (sh + side - 1u) / side + extra_rows, 1, 64u * waves_per_side * waves_per_side, 1, 1,
+                                 lds, stream, args, nullptr);
 }
 
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
@@ -206,7 +201,7 @@ hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, con
     if (n == 0) return hipSuccess;
     SceneView sc_arg = sc;
     void *args[] = { &sc_arg, &xyz, &n, &sd, &prim, &sd_march };
-    return hipModuleLaunchKernel(m.eval_sdf, (n + 255u) / 256u, 1, 1, 256, 1, 1, lds_bytes_of(sc), stream, args, nullptr);
+    return hipModuleLaunchKernel(m.eval_sdf, (n + 255u) / 256u, 1, 1, 256, 1, 1, sc.lattice_words * 4u, stream, args, nullptr);
 }
 
 }  // namespace rmdev

@@ -22,7 +22,6 @@ struct SceneModule {
     hipFunction_t trace = nullptr;
     hipFunction_t eval_sdf = nullptr;
     uint32_t points_per_lane = 0;   // of `trace`
-    uint32_t waves_per_group = 4;   // of `trace`: 4 (16 x 16 lanes) or 1 (8 x 8)
     double compile_seconds = 0.0;   // 0 when the code came from the process-wide cache
     bool loaded() const { return module != nullptr; }
     void unload();
@@ -31,8 +30,7 @@ struct SceneModule {
 // Compiles `source` (see codegen.cpp) for gfx950 and loads it on the current device.  Code objects
 // are cached per process by source text, so uploading the same scene again costs no compile.
 // Returns false and fills `log` on failure.
-bool compile_scene_module(const std::string &source, uint32_t points_per_lane, uint32_t waves_per_group, SceneModule &out,
-                          std::string &log);
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
 
 // Second-level cache of code objects on disk (null or "": none, the default).  Files are keyed by the
 // generated source and the device headers, written atomically, and verified against the full key on load.
@@ -41,7 +39,9 @@ void set_kernel_cache_dir(const char *dir);
 // The compile step alone (no device needed): true if `source` compiles for gfx950.
 bool check_scene_source(const std::string &source, std::string &log);
 
-hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, Sample *samples,
+// waves_per_side = 1, 2 or 3: workgroups of that many waves squared, tiles of 8 x that many samples per side.
+// LDS: the lattice tables and, when the kernel writes pixels (fr.pixels_*), the tile's sample colours.
+hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
                                WorkCounters *counters, hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                                   uint32_t *prim, float *sd_march, hipStream_t stream);

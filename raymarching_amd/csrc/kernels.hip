@@ -36,7 +36,7 @@ template <int kPts, int MIN_WAVES, bool COUNT, int kWaves>
 __global__ __launch_bounds__(64 * kWaves, MIN_WAVES) void trace_kernel(const SceneView sc, const FrameView fr,
                                                                        Sample *__restrict__ samples,
                                                                        WorkCounters *__restrict__ counters) {
-    trace_body<InterpretedScene, kPts, COUNT, kWaves>(sc, fr, samples, counters);
+    trace_body<InterpretedScene, kPts, COUNT>(sc, fr, samples, counters);
 }
 
 __global__ __launch_bounds__(256) void eval_sdf_kernel(const SceneView sc, const float *__restrict__ xyz, uint32_t n,

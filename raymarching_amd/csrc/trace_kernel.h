@@ -75,42 +75,57 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     }
 }
 
-// kPts = 2: block = 32 x 16 sub-samples, each wave a 16 x 8 tile, each lane two horizontally
-// adjacent samples that march in lockstep -- halves the scalar-unit cost per sample, which bounds
-// scenes of few records; a sample that finishes early idles until its partner is done.
-// kPts = 1: block = 16 x 16, wave = 8 x 8, one sample per lane -- for scenes whose cost is in long
-// primitive runs (vector-ALU bound), where idling would cost more than the scalar unit saves.
-// MIN_WAVES: waves per SIMD the register allocation must allow.
-template <class Scene, int kPts, bool COUNT, int kWaves = 4>
+// A workgroup is n x n waves (n = 1, 2 or 3, from the launch) and renders one tile of 8n x 8n samples (16n x 8n with two
+// samples per lane), each wave an 8 x 8 block of it.
+// kPts = 2: each lane two horizontally adjacent samples that march in lockstep -- halves the scalar-unit cost per
+// sample, which bounds scenes of few records; a sample that finishes early idles until its partner is done.
+// kPts = 1: one sample per lane -- for scenes whose cost is in long primitive runs or lattice walks (vector-ALU bound),
+// where idling would cost more than the scalar unit saves.
+//
+// Pixels from the trace kernel (FrameView::pixels_*): when the SSAA kernel k divides the tile's side, a tile holds whole
+// pixels; its samples meet in LDS and the wave that finishes last adds them up and writes the pixels (k = 1, 2, 4, 8:
+// one wave per tile; k = 3, 6, 12, 24: 3 x 3 waves).  No wave waits for another: each books its arrival with an LDS
+// atomic after its samples are in LDS and ends, unless it was the last.
+//
+// Tile parts (tile_order entries above kTileBits): quarter q of a tile is its (q & 1, q >> 1) sub-tile of half the
+// side, sixteenth q the (q & 3, q >> 2) sub-tile of a quarter of the side; the workgroup's waves split the sub-tile
+// among them as they split a tile, so a wave renders 4 x 4 or 2 x 2 samples on its first 16 or 4 lanes and waits
+// only for those.
+template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
-    __shared__ unsigned long long block_counts[6];
+    __shared__ uint32_t arrived;
+    if (threadIdx.x == 0) arrived = 0u;
     if (COUNT) {
-        if (threadIdx.x < 6) block_counts[threadIdx.x] = 0;
         if (threadIdx.x < 16) probe_words()[threadIdx.x] = 0;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t n_side = n_waves == 1u ? 1u : (n_waves == 4u ? 2u : 3u);   // waves per tile side
+    const uint32_t wave_x = n_side == 1u ? 0u : wave % n_side, wave_y = n_side == 1u ? 0u : wave / n_side;
+    const uint32_t tile_side = 8u * n_side;                                  // samples per tile side (x: times kPts)
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
-    // kWaves = 4: a workgroup is 2 x 2 waves of 8 x 8 lanes; kWaves = 1: one wave
-    constexpr uint32_t kSide = kWaves == 4 ? 2u : 1u;
     const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t n_tiles = gridDim.x * ((sh + 8u * kSide - 1u) / (8u * kSide));   // gridDim.x = tiles per row
-    if (slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;            // the last grid row's surplus
+    const uint32_t n_tiles = gridDim.x * ((sh + tile_side - 1u) / tile_side);   // gridDim.x = tiles per row
+    if (slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;         // the last grid row's surplus
     const Lds lds = stage_lds(sc);
     const unsigned long long started = fr.tile_cost ? wall_clock64() : 0ull;
     const uint32_t entry = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
-    const uint32_t tile = entry & kTileMask, part = (kWaves == 1 && kPts == 1) ? entry >> kTileBits : 0u;
+    const uint32_t tile = entry & kTileMask, part = kPts == 1 ? entry >> kTileBits : 0u;
     const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
-    // a whole tile: lane = 8 * row + column; quarter q: lanes 0..15 = 4 * row + column in the quarter
-    // part 1..4: quarter part - 1 (4 x 4 samples, lanes 0..15); part 5..20: sixteenth part - 5 (2 x 2 samples, lanes 0..3)
-    const uint32_t six = part - 5u;
-    const uint32_t col = part == 0u ? (lane & 7u) : (part < 5u ? ((part - 1u) & 1u) * 4u + (lane & 3u) : (six & 3u) * 2u + (lane & 1u));
-    const uint32_t row = part == 0u ? (lane >> 3) : (part < 5u ? ((part - 1u) >> 1) * 4u + ((lane >> 2) & 3u) : (six >> 2) * 2u + ((lane >> 1) & 1u));
-    const bool in_part = part == 0u || lane < (part < 5u ? 16u : 4u);
-    const uint32_t sx0 = tile_x * (8u * kSide * kPts) + (kWaves == 4 ? (wave & 1u) : 0u) * (8u * kPts) + col * (uint32_t)kPts;
-    const uint32_t sy = tile_y * (8u * kSide) + (kWaves == 4 ? (wave >> 1) : 0u) * 8u + row;
+    // the part's place in the tile, the wave's block in the part, the lane's sample in the block (all in samples)
+    const uint32_t split_log2 = part == 0u ? 0u : (part < 5u ? 1u : 2u);      // parts per tile side: 1, 2 or 4
+    const uint32_t q = part == 0u ? 0u : (part < 5u ? part - 1u : part - 5u);
+    const uint32_t block = 8u >> split_log2;                                  // the wave's block is block x block samples
+    const uint32_t part_side = tile_side >> split_log2;
+    const uint32_t part_x = (q & ((1u << split_log2) - 1u)) * part_side, part_y = (q >> split_log2) * part_side;
+    const uint32_t col = part_x + wave_x * block + (lane & (block - 1u));
+    const uint32_t row = part_y + wave_y * block + ((lane >> (3u - split_log2)) & (block - 1u));
+    const bool in_part = lane < block * block;
+    const uint32_t sx0 = (tile_x * tile_side + col) * (uint32_t)kPts;
+    const uint32_t sy = tile_y * tile_side + row;
     LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
@@ -274,65 +289,79 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         }
     }
 
-    // Whole pixels in the workgroup (see FrameView::pixels_f32): the samples meet in LDS and the lane of every
-    // pixel's first sample adds them up in the reference's order (render.cpp:103-112: i, the column, outer; j inner).
-    const bool fused = kWaves == 1 && kPts == 1 && (fr.pixels_f32 || fr.pixels_rgba8);
-    __shared__ float tile_rgb[kWaves == 1 && kPts == 1 ? 3 * 64 : 1];
+    // Whole pixels in the workgroup (see FrameView::pixels_f32): the samples meet in LDS and the wave that arrives last
+    // adds them up, every pixel in the reference's order (render.cpp:103-112: i, the column, outer; j inner).
+    const bool fused = kPts == 1 && (fr.pixels_f32 || fr.pixels_rgba8);
+    float *tile_rgb = reinterpret_cast<float *>(lds.park);   // [tile_side x tile_side][3], behind the lattice tables
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
         if (!stored[s] && !fused) continue;
         // scene::lighting's clamp (scene.cpp:60); the product with the colour is formed where the samples are added up
         Sample sample_out = { 0.0f, kNoPrim };
         if (live[s]) sample_out = Sample{ __builtin_fminf(__builtin_fmaxf(fr.saturation, lighting[s]), 1.0f), prim[s] };
-        if (kWaves == 1 && kPts == 1 && fused) {
-            const V3 color = sample_colour(sc.colors, sample_out);
+        if (fused) {
             if (in_part) {
-                float *mine = tile_rgb + 3u * (row * 8u + col);
+                const V3 color = sample_colour(sc.colors, sample_out);
+                float *mine = tile_rgb + 3u * (row * tile_side + col);
                 mine[0] = color.x;
                 mine[1] = color.y;
                 mine[2] = color.z;
-            }
-            __syncthreads();
-            if (stored[s] && sx0 % k == 0u && sy % k == 0u) {
-                float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-                for (uint32_t i = 0; i < k; ++i) {
-                    for (uint32_t j = 0; j < k; ++j) {
-                        const float *c = tile_rgb + 3u * ((row + j) * 8u + col + i);
-                        tx += c[0];
-                        ty += c[1];
-                        tz += c[2];
-                    }
-                }
-                store_pixel(tx, ty, tz, k, fr.width, sx0 / k, sy / k, fr.pixels_f32, fr.pixels_rgba8);
             }
         } else {
             samples[(size_t)sy * sw + sx0 + (uint32_t)s] = sample_out;
         }
     }
 
-    if (fr.tile_cost) {
-        // the workgroup's duration as its last wave sees it (waves of a workgroup start together)
-        __syncthreads();
-        if (threadIdx.x == 0) fr.tile_cost[tile] = (uint32_t)(wall_clock64() - started);
+    if (COUNT) {
+        // per wave: its lanes' sums, then one atomic per counter
+        unsigned long long sums[6] = { cnt.sdf, cnt.steps, cnt.rays, cnt.evals, cnt.slots, cnt.flops };
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            unsigned long long v = sums[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            sums[i] = v;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->sdf_calls, sums[0]);
+            atomicAdd(&counters->march_steps, sums[1]);
+            atomicAdd(&counters->rays, sums[2]);
+            atomicAdd(&counters->prim_evals, sums[3]);
+            atomicAdd(&counters->march_slots, sums[4]);
+            atomicAdd(&counters->flops, sums[5]);
+        }
     }
 
-    if (COUNT) {
-        atomicAdd(&block_counts[0], (unsigned long long)cnt.sdf);
-        atomicAdd(&block_counts[1], (unsigned long long)cnt.steps);
-        atomicAdd(&block_counts[2], (unsigned long long)cnt.rays);
-        atomicAdd(&block_counts[3], (unsigned long long)cnt.evals);
-        atomicAdd(&block_counts[4], (unsigned long long)cnt.slots);
-        atomicAdd(&block_counts[5], (unsigned long long)cnt.flops);
-        __syncthreads();
-        if (threadIdx.x < 16 && probe_words()[threadIdx.x]) atomicAdd(&counters->probe[threadIdx.x], probe_words()[threadIdx.x]);
-        if (threadIdx.x == 0) {
-            atomicAdd(&counters->sdf_calls, block_counts[0]);
-            atomicAdd(&counters->march_steps, block_counts[1]);
-            atomicAdd(&counters->rays, block_counts[2]);
-            atomicAdd(&counters->prim_evals, block_counts[3]);
-            atomicAdd(&counters->march_slots, block_counts[4]);
-            atomicAdd(&counters->flops, block_counts[5]);
+    // The wave's samples are in LDS (or on their way to memory): it books its arrival and ends, unless it is the
+    // workgroup's last, which writes the pixels and the tile's duration.
+    if (fr.tile_cost == nullptr && !fused && !COUNT) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t before = 0u;
+    if (lane == 0u) before = __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (before + 1u != n_waves) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (fused) {
+        const uint32_t pixels = part_side / k;                 // part_side is a multiple of k (the host lists no other parts)
+        for (uint32_t i = lane; i < pixels * pixels; i += 64u) {
+            const uint32_t px = i % pixels, py = i / pixels;
+            const uint32_t lx = part_x + px * k, lrow = part_y + py * k;          // the pixel's first sample, in the tile
+            const uint32_t gx = tile_x * tile_side + lx, gy = tile_y * tile_side + lrow;
+            if (gx >= sw || gy >= sh) continue;
+            float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+            for (uint32_t ii = 0; ii < k; ++ii) {
+                for (uint32_t jj = 0; jj < k; ++jj) {
+                    const float *c = tile_rgb + 3u * ((lrow + jj) * tile_side + lx + ii);
+                    tx += c[0];
+                    ty += c[1];
+                    tz += c[2];
+                }
+            }
+            store_pixel(tx, ty, tz, k, fr.width, gx / k, gy / k, fr.pixels_f32, fr.pixels_rgba8);
         }
+    }
+    if (fr.tile_cost && lane == 0u) fr.tile_cost[tile] = (uint32_t)(wall_clock64() - started);
+    if (COUNT) {
+        if (lane < 16u && probe_words()[lane]) atomicAdd(&counters->probe[lane], probe_words()[lane]);
     }
 }
 
