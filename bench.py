@@ -58,14 +58,7 @@ from raymarching_amd import sharding  # noqa: E402
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X datasheet: an FMA in every issue slot; code without fusable multiply-adds tops out near half of it
 VALU_ISSUE_CEILING_T = 69.0            # T lane-instructions/s the 13-instruction cross body sustains (tools/valu_bench.hip)
-WORKLOADS = {
-    # name: (scene file, params overrides, description)
-    "default": ("default.txt", dict(), "configs[1]: shipped scene (Menger iterations 3), 1024x768, SSAA 3x3, 2 lights"),
-    "menger2": ("menger2.txt", dict(kernel=1), "configs[0]: Menger iterations 2, 1024x768, SSAA 1, 2 lights"),
-    "uhd": ("default.txt", dict(width=3840, height=2160, kernel=4), "configs[2]: shipped scene, 3840x2160, SSAA 4x4, 2 lights"),
-    "closeup6": ("closeup6.txt", dict(), "configs[3]: Menger iterations 6 close-up, 1024x768, SSAA 3x3, 2 lights"),
-    "synthetic": ("synthetic1024.txt", dict(), "configs[4]: 1024 mixed primitives, 8 lights, 1024x768, SSAA 3x3"),
-}
+from tools.workloads import WORKLOADS  # noqa: E402  (name -> scene file, parameter overrides, description)
 
 
 def parse():
@@ -99,6 +92,8 @@ def parse():
                     help="N > 1: re-deal the bands to the ranks by measured cost (off by default: cyclic 4-row bands leave "
                          "under 2 %% of cost imbalance at N = 8 on the shipped scenes, tools/band_balance.py)")
     ap.add_argument("--band-rows", type=int, default=4, help="rows per band when sharding over GPUs")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the timing of frames delivered into host memory")
+    ap.add_argument("--no-first-frame-leg", action="store_true", help="skip the cold-start measurement in fresh processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive-leg", action="store_true")
     return ap.parse_args()
@@ -334,6 +329,11 @@ def main():
             rr.set_shading(False)
             for _ in range(3):                        # times the tiles of the new setting, then runs in cost order
                 rr.render_device(rows, None, sh.data_ptr())
+        all_kernel_ms = r.counters()["kernel_ms"]
+        r.set_counting(True)
+        r.render_device(rows, None, shard.data_ptr())
+        cnt_all_rays = r.counters()
+        r.set_counting(False)
         n_all = max(F, min(a.steps, 100))
         for i in range(F):
             frame(i, i == F - 1)
@@ -343,7 +343,13 @@ def main():
             frame(i, i == n_all - 1)
         drain()
         all_ms = (time.perf_counter() - t1) / n_all * 1e3
+        all_tflops = executed_flops(cnt_all_rays) / (all_kernel_ms * 1e-3) / 1e12
         all_marched = {"value": round(rays_per_frame / all_ms / 1e3, 3), "unit": "Mrays/s", "ms_per_step": round(all_ms, 4), "steps": n_all,
+                       "roofline": {"bound": "valu_fp32", "achieved": round(all_tflops, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(all_tflops / FP32_VECTOR_PEAK_TFLOPS, 4), "kernel_ms": round(all_kernel_ms, 4),
+                                    "achieved_frames_in_flight": round(executed_flops(cnt_all_rays) / (all_ms * 1e-3) / 1e12, 3),
+                                    "executed_flops_per_frame": executed_flops(cnt_all_rays), "sdf_calls_per_frame": cnt_all_rays["sdf_calls"],
+                                    "rays_cast_per_frame": cnt_all_rays["rays"]},
                        "note": "rm_set_shading(RM_SHADE_ALL): no sample skips its normal and shadow rays, no shadow ray stops past its "
                                "light; same frames, timed right after the main region in the same process"}
         for rr in rs:
@@ -403,6 +409,65 @@ def main():
         r.set_shading(a.shading == "coloured")
         r.set_scene(scene)
 
+    # ---- one frame at a time, and frames delivered into host memory (render::GPU's definition of a frame,
+    # render.cpp:468-475: dispatch + read-back), one GPU only; after the timed region
+    host = None
+    if world == 1 and not group and a.emulate_share <= 1 and not a.no_host_leg:
+        n_h = max(F, min(a.steps, 100))
+        t1 = time.perf_counter()
+        for _ in range(n_h):
+            r.render_device(rows, None, shard.data_ptr())
+        alone_ms = (time.perf_counter() - t1) / n_h * 1e3
+        bufs = [rm.HostBuffer((H, W, 4), "uint8") for _ in rs]
+        whole = rm.Rows(H, 0, 1, 1)
+        for rr, hb in zip(rs, bufs):
+            rr.enqueue_host(whole, None, hb.ptr)
+        drain()
+        t1 = time.perf_counter()
+        for i in range(n_h):
+            rs[i % F].enqueue_host(whole, None, bufs[i % F].ptr)
+        drain()
+        host_ms = (time.perf_counter() - t1) / n_h * 1e3
+        t1 = time.perf_counter()
+        for _ in range(n_h):
+            rm.lib().rm_render_rgba8(r._h, bufs[0].ptr)
+        host_alone_ms = (time.perf_counter() - t1) / n_h * 1e3
+        pageable = __import__("numpy").zeros((H, W, 4), "uint8")
+        t1 = time.perf_counter()
+        for _ in range(max(3, n_h // 4)):
+            rm.lib().rm_render_rgba8(r._h, pageable.ctypes.data)
+        pageable_ms = (time.perf_counter() - t1) / max(3, n_h // 4) * 1e3
+        single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        r.render_device(whole, None, single.data_ptr())
+        same = all(bool((torch.from_numpy(hb.array) == single.cpu()).all()) for hb in bufs)
+        host = {"value_host": round(rays_per_frame / host_ms / 1e3, 3), "unit": "Mrays/s", "frame_ms_host": round(host_ms, 4), "steps": n_h,
+                "frames_in_flight": F, "host_frames_equal_device_frame": same,
+                "frame_alone_ms": round(alone_ms, 4), "frame_alone_ms_host": round(host_alone_ms, 4),
+                "frame_alone_ms_host_pageable": round(pageable_ms, 4),
+                "note": "value_host: the same frames with every frame's RGBA8 image copied into page-locked host memory behind its kernels "
+                        "(rm_enqueue_host), frames in flight as in the main region; frame_alone_ms*: one frame at a time, wall clock "
+                        "per synchronous call (rm_render_device / rm_render_rgba8 into page-locked / pageable memory)"}
+        for hb in bufs:
+            hb.free()
+    # ---- cold start: a fresh process uploads the scene and renders its first frame, with an empty cache directory
+    # and again with what the first run left in it (compiled kernels, measured tile order)
+    first = None
+    if world == 1 and rank == 0 and not group and a.emulate_share <= 1 and not a.no_first_frame_leg:
+        import subprocess
+        import tempfile
+        import shutil
+        d = tempfile.mkdtemp(prefix="rm_bench_cache_")
+        try:
+            runs = []
+            for _ in range(2):
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_frame.py"), a.workload, d],
+                                     capture_output=True, text=True, timeout=300)
+                runs.append(json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": out.stderr[-300:]})
+            first = {"empty_cache": runs[0], "warm_cache": runs[1],
+                     "note": "tools/first_frame.py in a fresh process: rm_set_scene, then three rm_render_rgba8 into page-locked memory"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_per_frame * a.steps / elapsed / 1e6
@@ -459,6 +524,9 @@ def main():
             "host_issue_ms_per_frame": round(host_issue_ms, 4),
             "mrays_cast_per_s": round(total_rays * a.steps / elapsed / 1e6, 3),
             "every_ray_marched": all_marched,
+            "host_image": host,
+            "first_frame": first,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }
         if exhaustive:

@@ -125,6 +125,11 @@ int rm_destroy(rm_context *ctx);
 /* Replaces render::pushuniforms (render.cpp:368-391). */
 int rm_set_params(rm_context *ctx, const rm_params *params);
 
+/* Replaces render::setup::buffers (render.cpp:439-445): sizes the device buffers whole-frame renders of the current
+ * parameters need (frame, SSAA samples, tile tables), so that the first frame does not pay for them.  Optional: every
+ * render sizes what it lacks. */
+int rm_reserve(rm_context *ctx);
+
 /* Replaces render::push's scene part: genscene + genlights + 3x pushssbo and the
  * camera uniforms (render.cpp:393-404, 447-466).  transform is the camera's
  * 4x4 matrix, column-major (packmatrix, render.cpp:281-286). */
@@ -140,6 +145,23 @@ int rm_render_rgba8(rm_context *ctx, uint8_t *host_image);
 /* Same frame as float RGBA (the CPU operators' Image2D<float4>, render.cpp:119),
  * width*height*4 floats. */
 int rm_render_f32(rm_context *ctx, float *host_image);
+
+/*
+ * render::GPU's read-back (glGetTexImage, render.cpp:474) without the wait: queues the kernels of the given row bands
+ * and, behind them on the context's stream, the copy of the finished rows into the caller's HOST buffers (either may
+ * be NULL; rows * width * 4 floats / bytes), and returns; rm_wait completes the frame.  With page-locked host memory
+ * -- from rm_host_alloc, or the caller's own buffer passed through rm_host_register once -- the copy runs on the copy
+ * engine while other contexts' kernels use the GPU, so frames in flight on several contexts deliver host images at
+ * nearly the device-resident rate; with ordinary pageable memory the copy is staged by the runtime and slower.
+ * rm_render_rgba8 / rm_render_f32 are this plus rm_wait for the whole frame (and time the tiles of a new configuration).
+ */
+int rm_enqueue_host(rm_context *ctx, const rm_rows *rows, float *host_f32, uint8_t *host_rgba8);
+/* Page-locked host memory for the frames (hipHostMalloc / hipHostFree behind a C signature, for callers without HIP
+ * headers), and page-locking of a buffer the caller owns (hipHostRegister / hipHostUnregister; unregister before freeing). */
+int rm_host_alloc(size_t bytes, void **out);
+int rm_host_free(void *ptr);
+int rm_host_register(void *ptr, size_t bytes);
+int rm_host_unregister(void *ptr);
 
 /* Renders the given row bands into caller-owned DEVICE buffers (either may be
  * NULL): device_f32 holds rows*width*4 floats, device_rgba8 rows*width*4 bytes,
@@ -177,7 +199,9 @@ int rm_set_stream(rm_context *ctx, void *hip_stream);
  * trace kernel does not write the pixels itself -- lives in a static device array of RM_STATIC_SCRATCH_BYTES
  * that every GPU the library runs on holds from the first rm_create on it until the process ends.
  *   - A render whose sample image (band_count * band_rows * kernel rows of width * kernel samples) exceeds
- *     the array is refused with RM_ERR_INVALID; render fewer rows per call.
+ *     the array is refused with RM_ERR_INVALID (render fewer rows per call) -- unless the scene has kernels of
+ *     its own (RM_KERNEL_COMPILED) and the SSAA kernel is 3, 6, 12 or 24: the trace kernel then runs workgroups
+ *     of 3 x 3 waves that hold whole pixels and write them themselves, slower but without a sample image.
  *   - Tiles run in the order an earlier rm_render_device of the same configuration measured, if this context
  *     holds one, in row-major order otherwise; this call never times tiles.  With work counting on it is
  *     refused (RM_ERR_STATE).

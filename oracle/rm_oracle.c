@@ -36,12 +36,25 @@ static inline f3 f3_add(f3 a, f3 b) { return f3_make(a.x + b.x, a.y + b.y, a.z +
 static inline f3 f3_sub(f3 a, f3 b) { return f3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline f3 f3_scale(f3 a, float s) { return f3_make(a.x * s, a.y * s, a.z * s); }
 static inline f3 f3_divs(f3 a, float s) { return f3_make(a.x / s, a.y / s, a.z / s); }
-static inline float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* Deliberately WRONG forms of three operations, selected by rmo_params.variant: the tests use them to show that
+ * the reference's committed render tells the forms used here from these (a pin that every variant passed would pin
+ * nothing).  Thread-local because the scene SDF has no parameter block; set per pixel from the parameters. */
+enum { VARIANT_CROSS_MEDIAN = 1, VARIANT_LERP_WEIGHTED = 2, VARIANT_DOT_FUSED = 4 };
+static _Thread_local uint32_t tl_variant;
+
+static inline float f3_dot(f3 a, f3 b) {
+    if (tl_variant & VARIANT_DOT_FUSED) return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));   /* what -ffp-contract=fast would make of it */
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 static inline float f3_length(f3 a) { return sqrtf(f3_dot(a, a)); }
 static inline f3 f3_cross(f3 a, f3 b) {
     return f3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-static inline float f_lerp(float u, float v, float t) { return u + t * (v - u); }
+static inline float f_lerp(float u, float v, float t) {
+    if (tl_variant & VARIANT_LERP_WEIGHTED) return (1.0f - t) * u + t * v;
+    return u + t * (v - u);
+}
+
 /* std::min / std::max on floats */
 static inline float f_min(float a, float b) { return (b < a) ? b : a; }
 static inline float f_max(float a, float b) { return (a < b) ? b : a; }
@@ -177,6 +190,8 @@ static inline float prim_sdf(const rmo_body *b, f3 p) {
     }
     float dmin = f_min(f_min(d.x, d.y), d.z);
     float dmax = f_max(f_max(d.x, d.y), d.z);
+    if (tl_variant & VARIANT_CROSS_MEDIAN)   /* the exact median, which the reference's rounded sum is not */
+        return f_max(f_min(d.x, d.y), f_min(f_max(d.x, d.y), d.z));
     return d.x + d.y + d.z - dmin - dmax;
 }
 
@@ -554,12 +569,14 @@ void rmo_default_params(rmo_params *p) {
     p->width = 1024; p->height = 768; p->kernel = 3; p->iterations = 1000;
     p->saturation = 0.05f; p->surface_eps = 1e-3f; p->offset_eps = 1e-3f;
     p->normalize_div = 0;
+    p->variant = 0;
 }
 
 /* render::pixel, /root/reference/source/render.cpp:82-120.
  * samples (optional) receives the k*k per-sample colours in loop order. */
 static void render_pixel(const rmo_scene *sc, const rmo_params *pr, int px, int py,
                          float *rgba_out, float *samples) {
+    tl_variant = pr->variant;
     const float AR = (float)pr->width / (float)pr->height;
     float w = sc->focal;
     float h = w / AR;

@@ -39,6 +39,7 @@ typedef struct rmo_params {
     float    surface_eps;  /* constants::precision::surface (1e-3f) */
     float    offset_eps;   /* constants::precision::offset  (1e-3f) */
     int32_t  normalize_div;/* 0: a*(1/len) (LiteMath), 1: a/len          */
+    uint32_t variant;      /* 0; tests only: bit 0 cross = exact median, bit 1 lerp = (1-t)u + tv, bit 2 fused dot products */
 } rmo_params;
 
 typedef struct rmo_counters {

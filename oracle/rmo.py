@@ -18,7 +18,7 @@ class Params(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32), ("kernel", C.c_uint32),
         ("iterations", C.c_int32), ("saturation", C.c_float),
         ("surface_eps", C.c_float), ("offset_eps", C.c_float),
-        ("normalize_div", C.c_int32),
+        ("normalize_div", C.c_int32), ("variant", C.c_uint32),
     ]
 
 

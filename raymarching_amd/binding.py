@@ -8,8 +8,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
-    "rm_create", "rm_destroy", "rm_set_params", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_create", "rm_destroy", "rm_set_params", "rm_reserve", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
+    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -74,11 +74,17 @@ def lib():
     L.rm_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.rm_destroy.argtypes = [vp]
     L.rm_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.rm_reserve.argtypes = [vp]
     L.rm_set_scene.argtypes = [vp, C.POINTER(Node), C.c_uint32, vp, C.c_uint32, vp, C.c_float]
     L.rm_render_rgba8.argtypes = [vp, vp]
     L.rm_render_f32.argtypes = [vp, vp]
     L.rm_render_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
     L.rm_enqueue_device.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_enqueue_host.argtypes = [vp, C.POINTER(Rows), vp, vp]
+    L.rm_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.rm_host_free.argtypes = [vp]
+    L.rm_host_register.argtypes = [vp, C.c_size_t]
+    L.rm_host_unregister.argtypes = [vp]
     L.rm_enqueue_device_static.argtypes = [vp, C.POINTER(Rows), vp, vp]
     L.rm_static_scratch_bytes.restype = C.c_size_t
     L.rm_wait.argtypes = [vp]
@@ -213,6 +219,9 @@ class Renderer:
         _check(lib().rm_set_params(self._h, C.byref(params)), "rm_set_params")
         self.params = params
 
+    def reserve(self):
+        _check(lib().rm_reserve(self._h), "rm_reserve")
+
     def set_scene(self, scene):
         _check(lib().rm_set_scene_from(self._h, scene.handle), "rm_set_scene_from")
 
@@ -242,6 +251,10 @@ class Renderer:
     def enqueue_device(self, rows, f32_ptr=None, rgba8_ptr=None):
         """render_device without waiting; pair with wait()."""
         _check(lib().rm_enqueue_device(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_enqueue_device")
+
+    def enqueue_host(self, rows, f32_ptr=None, rgba8_ptr=None):
+        """Queues a frame whose finished rows are copied into host memory at the given addresses; pair with wait()."""
+        _check(lib().rm_enqueue_host(self._h, C.byref(rows), f32_ptr, rgba8_ptr), "rm_enqueue_host")
 
     def enqueue_device_static(self, rows, f32_ptr=None, rgba8_ptr=None):
         """enqueue_device through the library's static scratch: the call allocates nothing."""
@@ -314,6 +327,27 @@ class Renderer:
     @property
     def stream(self):
         return lib().rm_stream(self._h)
+
+
+class HostBuffer:
+    """Page-locked host memory from rm_host_alloc, seen as a numpy array."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        _check(lib().rm_host_alloc(self.nbytes, C.byref(self._p)), "rm_host_alloc")
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p.value), dtype=self.dtype).reshape(self.shape)
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def free(self):
+        if self._p:
+            self.array = None
+            _check(lib().rm_host_free(self._p), "rm_host_free")
+            self._p = C.c_void_p()
 
 
 def write_png(path, rgba):

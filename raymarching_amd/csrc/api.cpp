@@ -26,6 +26,8 @@
 // The static scratch of rm_enqueue_device_static (see find_static_scratch below).
 static __device__ __align__(256) unsigned char scratch[RM_STATIC_SCRATCH_BYTES];
 
+int rm_write_png_file(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);   // png.cpp
+
 namespace {
 
 thread_local std::string g_error;
@@ -94,6 +96,27 @@ void *static_scratch(int device) {
     return g_scratch_of_device[device];
 }
 
+// Page-locked host words for the tile tables on their way to and from the device: a copy from ordinary memory makes the
+// runtime set up staging buffers of its own the first time (milliseconds, inside the first frame).
+struct PinnedWords {
+    uint32_t *ptr = nullptr;
+    size_t capacity = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= capacity && ptr) return hipSuccess;
+        release();
+        if (n == 0) n = 1;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) capacity = n;
+        else ptr = nullptr;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+    }
+};
+
 }  // namespace
 
 struct rm_context {
@@ -132,13 +155,16 @@ struct rm_context {
     int tile_scheduling = RM_TILES_BY_COST;
     int shading = RM_SHADE_COLOURED;
     uint64_t scene_serial = 0;
+    std::string scene_fingerprint;   // bytes that identify the uploaded scene, camera and lights (keys cached tile orders)
     OrderKey order_key{};
     bool order_ready = false;
     uint32_t measured_tiles_x = 0, measured_tiles_y = 0;
     DeviceArray<uint32_t> d_band_list;
+    std::vector<uint32_t> band_list_host;
     uint32_t band_list_size = 0;   // 0: bands are first_band + b * band_stride
     uint64_t band_list_serial = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
+    PinnedWords h_tiles;   // staging of both
     uint32_t order_extra = 0;        // entries of d_tile_order beyond one per tile (quarters of the longest tiles)
 
     // the frame enqueued last and not yet booked by finish_bands
@@ -164,6 +190,18 @@ namespace {
 constexpr int kCompiledPts = 1, kCompiledWaves = 4;
 constexpr size_t kSixteenthTiles = 16, kQuarterTiles = 32;   // how many of the longest tiles are launched in 16 and in 4 parts
 
+// What a measured tile order depends on, as bytes: the scene as uploaded (records, tables, camera, lights), the
+// parameters, the row bands and the launch shape.  Keys the tile orders kept in the kernel cache directory, so that
+// the first frame of a configuration some earlier process has rendered starts in cost order without being timed.
+std::string order_cache_key(const rm_context *ctx, const rm_context::OrderKey &key, const std::vector<uint32_t> &band_list) {
+    std::string k = ctx->scene_fingerprint;
+    rm_context::OrderKey plain = key;
+    plain.scene_serial = plain.band_list_serial = 0;   // process-local counters
+    k.append(reinterpret_cast<const char *>(&plain), sizeof plain);
+    if (!band_list.empty()) k.append(reinterpret_cast<const char *>(band_list.data()), band_list.size() * sizeof(uint32_t));
+    return k;
+}
+
 int check_ready(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (!ctx->have_params) return fail(RM_ERR_STATE, "rm_set_params has not been called");
@@ -183,6 +221,31 @@ rmdev::FrameView frame_view(const rm_params &p, const rm_rows &rows) {
 // Trace + resolve of the given bands into device buffers; synchronises the stream.
 // Puts trace + resolve of the given bands on the context's stream.  may_measure: this frame may run in
 // natural tile order with every tile timed (its caller will call finish_bands before the next frame).
+// A tile order an earlier process measured for exactly this configuration, from the cache directory.
+bool load_tile_order(rm_context *ctx, const rm_context::OrderKey &key, size_t n_tiles) {
+    std::vector<uint32_t> entries;
+    if (!rmdev::load_cached_blob("tile-order:", order_cache_key(ctx, key, ctx->band_list_host), entries)) return false;
+    if (entries.size() < n_tiles || entries.size() > n_tiles * 16u) return false;
+    // every tile must be covered exactly: whole, or as its 4 quarters, or as its 16 sixteenths (a damaged file must
+    // not leave pixels unrendered)
+    std::vector<uint32_t> covered(n_tiles, 0u);
+    for (uint32_t e : entries) {
+        const uint32_t tile = e & rmdev::kTileMask, part = e >> rmdev::kTileBits;
+        if (tile >= n_tiles || part > 20u) return false;
+        covered[tile] += part == 0u ? 16u : (part < 5u ? 4u : 1u);
+    }
+    for (uint32_t c : covered)
+        if (c != 16u) return false;
+    if (ctx->d_tile_order.reserve(entries.size()) != hipSuccess || ctx->h_tiles.reserve(entries.size()) != hipSuccess) return false;
+    std::memcpy(ctx->h_tiles.ptr, entries.data(), entries.size() * sizeof(uint32_t));
+    // ordered before the launch that follows on the same stream; the staging words stay untouched until that frame is waited for
+    if (hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+    ctx->order_extra = (uint32_t)(entries.size() - n_tiles);
+    ctx->order_key = key;
+    ctx->order_ready = true;
+    return true;
+}
+
 // static_samples: the device's static scratch (rm_enqueue_device_static) -- the call then allocates nothing: the sample
 // image goes there, tiles are never timed, and a configuration that would need a buffer the context does not hold is refused.
 int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure,
@@ -254,6 +317,10 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             fr.tile_order = ctx->d_tile_order.ptr;
             fr.extra_slots = ctx->order_extra;
             pend.by_cost = true;
+        } else if (may_measure && load_tile_order(ctx, key, pend.n_tiles)) {
+            fr.tile_order = ctx->d_tile_order.ptr;
+            fr.extra_slots = ctx->order_extra;
+            pend.by_cost = true;
         } else if (may_measure) {
             ctx->order_key = key;
             ctx->order_ready = false;
@@ -303,10 +370,26 @@ int finish_bands(rm_context *ctx) {
     RM_HIP(hipEventElapsedTime(&ms_trace, ctx->ev[0], ctx->ev[1]));
     RM_HIP(hipEventElapsedTime(&ms_resolve, ctx->ev[1], ctx->ev[2]));
     if (pend.measuring) {
-        std::vector<uint32_t> cost(pend.n_tiles), order(pend.n_tiles);
-        RM_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost.ptr, pend.n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        std::vector<uint32_t> order(pend.n_tiles);
+        RM_HIP(ctx->h_tiles.reserve(pend.n_tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
+        RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, pend.n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
+        const std::vector<uint32_t> cost(ctx->h_tiles.ptr, ctx->h_tiles.ptr + pend.n_tiles);
+        // by falling cost, ties in tile order: three stable counting passes over 11-bit digits of the inverted cost
+        // (a comparison sort of the shipped frame's 110 592 tiles took 6 ms, ten frames' worth)
+        {
+            std::vector<uint32_t> from(pend.n_tiles), count(2048);
+            std::iota(order.begin(), order.end(), 0u);
+            for (int pass = 0; pass < 3; pass++) {
+                const int shift = 11 * pass;
+                std::fill(count.begin(), count.end(), 0u);
+                for (uint32_t t : order) count[(~cost[t] >> shift) & 2047u]++;
+                uint32_t at = 0;
+                for (uint32_t &c : count) { const uint32_t n = c; c = at; at += n; }
+                from.swap(order);
+                for (uint32_t t : from) order[count[(~cost[t] >> shift) & 2047u]++] = t;
+            }
+        }
         // The frame cannot end before its longest tile does.  The tiles that ran longest -- a few dozen, where a few rays
         // take hundreds of expensive steps -- are listed as 16 or 4 workgroups, each of which waits only for its own
         // samples: measured on the shipped frame, 0.85 -> 0.62 ms alone on the GPU.  By rank, because the measured
@@ -330,9 +413,12 @@ int finish_bands(rm_context *ctx) {
             }
             rank++;
         }
-        RM_HIP(hipMemcpy(ctx->d_tile_order.ptr, entries.data(), entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::memcpy(ctx->h_tiles.ptr, entries.data(), entries.size() * sizeof(uint32_t));
+        RM_HIP(hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
         ctx->order_extra = (uint32_t)(entries.size() - order.size());
         ctx->order_ready = true;
+        rmdev::store_cached_blob("tile-order:", order_cache_key(ctx, ctx->order_key, ctx->band_list_host), entries);
     }
     ctx->last = rm_counters{};
     ctx->last.tiles_by_cost = pend.by_cost ? 1u : 0u;
@@ -387,6 +473,7 @@ int rm_create(int device, rm_context **out) {
     if (!ctx) return fail(RM_ERR_INVALID, "rm_create: out of host memory");
     ctx->device = device;
     hipError_t e = find_static_scratch(device);
+    if (e == hipSuccess) e = rmdev::preload_kernels();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
@@ -407,7 +494,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_frame_rgba8.release(); ctx->d_counters.release(); ctx->d_points.release();
     ctx->module.unload();
     ctx->counting_module.unload();
-    ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release();
+    ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release(); ctx->h_tiles.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -424,6 +511,35 @@ int rm_set_params(rm_context *ctx, const rm_params *params) {
         return fail(RM_ERR_INVALID, "rm_set_params: image too large");
     ctx->params = *params;
     ctx->have_params = true;
+    return RM_OK;
+}
+
+int rm_reserve(rm_context *ctx) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (!ctx->have_params) return fail(RM_ERR_STATE, "rm_set_params has not been called");
+    RM_HIP(hipSetDevice(ctx->device));
+    const rm_params &p = ctx->params;
+    const size_t pixels = (size_t)p.width * p.height;
+    RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
+    RM_HIP(ctx->d_frame_f32.reserve(pixels * 4));
+    const size_t samples = pixels * p.kernel * p.kernel;
+    // the sample image, unless the scene's own kernel will write the pixels (not known before the scene is)
+    const bool writes_pixels = ctx->have_scene && ctx->module.loaded() && (8u * (ctx->program.lattice.size() > 1024 ? 2u : 1u)) % p.kernel == 0u;
+    if (!writes_pixels) RM_HIP(ctx->d_samples.reserve(samples));
+    const size_t tiles = ((size_t)p.width * p.kernel + 7u) / 8u * (((size_t)p.height * p.kernel + 7u) / 8u);
+    RM_HIP(ctx->d_tile_cost.reserve(tiles));
+    RM_HIP(ctx->d_tile_order.reserve(tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
+    RM_HIP(ctx->h_tiles.reserve(tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
+    // first use by the GPU is what makes fresh device memory resident (milliseconds for a frame's worth): now, not in the first frame
+    RM_HIP(hipMemsetAsync(ctx->d_frame_rgba8.ptr, 0, pixels * 4, ctx->stream));
+    RM_HIP(hipMemsetAsync(ctx->d_frame_f32.ptr, 0, pixels * 4 * sizeof(float), ctx->stream));
+    if (!writes_pixels) RM_HIP(hipMemsetAsync(ctx->d_samples.ptr, 0, samples * sizeof(rmdev::Sample), ctx->stream));
+    RM_HIP(hipMemsetAsync(ctx->d_tile_cost.ptr, 0, tiles * sizeof(uint32_t), ctx->stream));
+    // ... and the first copy in either direction between page-locked host memory and the device sets up the copy path (6 ms measured)
+    std::memset(ctx->h_tiles.ptr, 0, tiles * sizeof(uint32_t));
+    RM_HIP(hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, tiles * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
     return RM_OK;
 }
 
@@ -471,6 +587,21 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;
     ctx->scene_serial++;
+    {
+        std::string &fp = ctx->scene_fingerprint;
+        fp.clear();
+        auto add = [&fp](const void *data, size_t bytes) { fp.append(static_cast<const char *>(data), bytes); };
+        const rmdev::HostProgram &hp = ctx->program;
+        add(hp.recs.data(), hp.recs.size() * sizeof(rmdev::Rec));
+        add(hp.pa.data(), hp.pa.size() * sizeof(rmdev::Float4));
+        add(hp.pb.data(), hp.pb.size() * sizeof(rmdev::Float4));
+        add(hp.colors.data(), hp.colors.size() * sizeof(rmdev::Float4));
+        add(hp.lattice.data(), hp.lattice.size() * sizeof(uint32_t));
+        add(camera, sizeof camera);
+        add(lights.data(), lights.size() * sizeof(rmdev::Float4));
+        const int modes[2] = { ctx->kernel_mode, ctx->evaluator };
+        add(modes, sizeof modes);
+    }
     ctx->module.unload();
     ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
@@ -482,6 +613,20 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         }
     }
     ctx->have_scene = true;
+    if (ctx->module.loaded()) {
+        // The first launch of a freshly loaded kernel costs milliseconds (code upload, queue set-up): one pixel now, where
+        // the reference compiles its shader, instead of inside the first frame.
+        rmdev::FrameView fr{};
+        fr.width = fr.height = fr.kernel = 1u;
+        fr.iterations = 1;
+        fr.surface_eps = fr.offset_eps = 1e-3f;
+        fr.band_rows = fr.band_stride = fr.band_count = 1u;
+        if (void *spare = static_scratch(ctx->device)) {
+            RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, static_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
+            RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, static_cast<rmdev::Sample *>(spare), nullptr, static_cast<unsigned char *>(spare) + 256, ctx->stream));
+            RM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
     return RM_OK;
 }
 
@@ -521,28 +666,75 @@ int rm_set_stream(rm_context *ctx, void *hip_stream) {
     return RM_OK;
 }
 
+int rm_enqueue_host(rm_context *ctx, const rm_rows *rows, float *host_f32, uint8_t *host_rgba8) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_host: null rows");
+    if (!host_f32 && !host_rgba8) return fail(RM_ERR_INVALID, "rm_enqueue_host: no output buffer");
+    const size_t pixels = (size_t)rows->band_count * rows->band_rows * ctx->params.width;
+    RM_HIP(hipSetDevice(ctx->device));
+    if (host_f32) RM_HIP(ctx->d_frame_f32.reserve(pixels * 4));
+    if (host_rgba8) RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
+    if (int rc = enqueue_bands(ctx, *rows, host_f32 ? ctx->d_frame_f32.ptr : nullptr, host_rgba8 ? ctx->d_frame_rgba8.ptr : nullptr, false))
+        return rc;
+    // behind the kernels on the context's stream; with page-locked host memory (rm_host_alloc, rm_host_register) the
+    // copies run on the copy engine while other streams' kernels have the CUs
+    if (host_f32) RM_HIP(hipMemcpyAsync(host_f32, ctx->d_frame_f32.ptr, pixels * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (host_rgba8) RM_HIP(hipMemcpyAsync(host_rgba8, ctx->d_frame_rgba8.ptr, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return RM_OK;
+}
+
+int rm_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(RM_ERR_INVALID, "rm_host_alloc: null output pointer");
+    *out = nullptr;
+    RM_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RM_OK;
+}
+
+int rm_host_free(void *ptr) {
+    if (ptr) RM_HIP(hipHostFree(ptr));
+    return RM_OK;
+}
+
+int rm_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(RM_ERR_INVALID, "rm_host_register: null or empty range");
+    RM_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return RM_OK;
+}
+
+int rm_host_unregister(void *ptr) {
+    if (ptr) RM_HIP(hipHostUnregister(ptr));
+    return RM_OK;
+}
+
+namespace {
+
+// The whole frame into host memory, synchronously: the first render of a configuration times its tiles (device
+// buffers), every render ends with the copy behind the kernels on the context's stream.
+int render_host(rm_context *ctx, float *host_f32, uint8_t *host_rgba8) {
+    const rm_rows whole = { ctx->params.height, 0, 1, 1 };
+    const size_t pixels = (size_t)ctx->params.width * ctx->params.height;
+    RM_HIP(hipSetDevice(ctx->device));
+    if (host_f32) RM_HIP(ctx->d_frame_f32.reserve(pixels * 4));
+    if (host_rgba8) RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
+    if (int rc = enqueue_bands(ctx, whole, host_f32 ? ctx->d_frame_f32.ptr : nullptr, host_rgba8 ? ctx->d_frame_rgba8.ptr : nullptr, true))
+        return rc;
+    if (host_f32) RM_HIP(hipMemcpyAsync(host_f32, ctx->d_frame_f32.ptr, pixels * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (host_rgba8) RM_HIP(hipMemcpyAsync(host_rgba8, ctx->d_frame_rgba8.ptr, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_bands(ctx);
+}
+
+}  // namespace
+
 int rm_render_rgba8(rm_context *ctx, uint8_t *host_image) {
     if (int rc = check_ready(ctx)) return rc;
     if (!host_image) return fail(RM_ERR_INVALID, "rm_render_rgba8: null image");
-    const size_t bytes = (size_t)ctx->params.width * ctx->params.height * 4;
-    RM_HIP(hipSetDevice(ctx->device));
-    RM_HIP(ctx->d_frame_rgba8.reserve(bytes));
-    const rm_rows whole = { ctx->params.height, 0, 1, 1 };
-    if (int rc = render_bands(ctx, whole, nullptr, ctx->d_frame_rgba8.ptr)) return rc;
-    RM_HIP(hipMemcpy(host_image, ctx->d_frame_rgba8.ptr, bytes, hipMemcpyDeviceToHost));
-    return RM_OK;
+    return render_host(ctx, nullptr, host_image);
 }
 
 int rm_render_f32(rm_context *ctx, float *host_image) {
     if (int rc = check_ready(ctx)) return rc;
     if (!host_image) return fail(RM_ERR_INVALID, "rm_render_f32: null image");
-    const size_t n = (size_t)ctx->params.width * ctx->params.height * 4;
-    RM_HIP(hipSetDevice(ctx->device));
-    RM_HIP(ctx->d_frame_f32.reserve(n));
-    const rm_rows whole = { ctx->params.height, 0, 1, 1 };
-    if (int rc = render_bands(ctx, whole, ctx->d_frame_f32.ptr, nullptr)) return rc;
-    RM_HIP(hipMemcpy(host_image, ctx->d_frame_f32.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
-    return RM_OK;
+    return render_host(ctx, host_image, nullptr);
 }
 
 namespace {
@@ -643,6 +835,7 @@ int rm_set_band_list(rm_context *ctx, const uint32_t *image_bands, uint32_t coun
         RM_HIP(ctx->d_band_list.reserve(count));
         RM_HIP(hipMemcpy(ctx->d_band_list.ptr, image_bands, count * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    ctx->band_list_host.assign(image_bands, image_bands + count);
     ctx->band_list_size = count;
     ctx->band_list_serial++;
     return RM_OK;
@@ -675,6 +868,13 @@ int rm_get_counters(rm_context *ctx, rm_counters *out) {
 }
 
 void *rm_stream(rm_context *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+int rm_write_png(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height) {
+    const int rc = rm_write_png_file(path, rgba, width, height);
+    if (rc == RM_ERR_INVALID) return fail(RM_ERR_INVALID, "rm_write_png: null path or image, or an empty image");
+    if (rc != RM_OK) return fail(RM_ERR_IO, std::string("rm_write_png: cannot write ") + path);
+    return RM_OK;
+}
 
 // ---- host scene library ----------------------------------------------------
 

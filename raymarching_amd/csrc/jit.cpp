@@ -6,7 +6,11 @@
 
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <cerrno>
+#include <cstdlib>
 
 #include <chrono>
 #include <cstdio>
@@ -22,7 +26,40 @@ namespace {
 using CodeObject = std::shared_ptr<const std::vector<char>>;
 std::mutex g_cache_lock;
 std::unordered_map<std::string, CodeObject> g_cache;   // source text -> gfx950 code object
-std::string g_cache_dir;                                // optional second level on disk ("" = none)
+std::string g_cache_dir;                                // second level on disk ("" = none)
+bool g_cache_dir_chosen = false;                        // set_kernel_cache_dir was called, or the default was looked up
+
+// A directory of the calling user's that can be created and written: the cache's default place.
+bool usable_dir(const std::string &dir) {
+    if (dir.empty()) return false;
+    std::string at;
+    for (size_t i = 0; i <= dir.size(); i++) {            // mkdir -p, directories private to the user
+        if (i == dir.size() || (dir[i] == '/' && i > 0)) {
+            at = dir.substr(0, i);
+            if (mkdir(at.c_str(), 0700) != 0 && errno != EEXIST) return false;
+        }
+    }
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;   // never load code another user could have put there
+    return access(dir.c_str(), W_OK | X_OK) == 0;
+}
+
+// $RM_KERNEL_CACHE_DIR ("" or "off": none), else $XDG_CACHE_HOME/raymarch_hip, $HOME/.cache/raymarch_hip, /tmp/raymarch_hip-<uid>.
+std::string default_cache_dir() {
+    if (const char *env = std::getenv("RM_KERNEL_CACHE_DIR")) {
+        const std::string v = env;
+        if (v.empty() || v == "off") return "";
+        return usable_dir(v) ? v : "";
+    }
+    std::vector<std::string> candidates;
+    if (const char *xdg = std::getenv("XDG_CACHE_HOME")) if (*xdg) candidates.push_back(std::string(xdg) + "/raymarch_hip");
+    if (const char *home = std::getenv("HOME")) if (*home) candidates.push_back(std::string(home) + "/.cache/raymarch_hip");
+    candidates.push_back("/tmp/raymarch_hip-" + std::to_string((long long)geteuid()));
+    for (const std::string &c : candidates)
+        if (usable_dir(c)) return c;
+    return "";
+}
 
 // FNV-1a over the source and the embedded headers: names a code object file.  The file also holds
 // the full key text, compared on load, so a hash collision costs a recompile, never a wrong kernel.
@@ -37,18 +74,28 @@ std::string cache_key_text(const std::string &source) {
     return key;
 }
 
-std::string cache_file(const std::string &key) {
+std::string cache_dir() {
+    std::lock_guard<std::mutex> hold(g_cache_lock);
+    if (!g_cache_dir_chosen) {
+        g_cache_dir = default_cache_dir();
+        g_cache_dir_chosen = true;
+    }
+    return g_cache_dir;
+}
+
+std::string cache_file(const std::string &dir, const std::string &key) {
     unsigned long long h = 1469598103934665603ull;
     for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
     char name[64];
     std::snprintf(name, sizeof name, "/rm_%016llx.gfx950.bin", h);
-    return g_cache_dir + name;
+    return dir + name;
 }
 
 CodeObject load_from_disk(const std::string &source) {
-    if (g_cache_dir.empty()) return nullptr;
+    const std::string dir = cache_dir();
+    if (dir.empty()) return nullptr;
     const std::string key = cache_key_text(source);
-    std::FILE *f = std::fopen(cache_file(key).c_str(), "rb");
+    std::FILE *f = std::fopen(cache_file(dir, key).c_str(), "rb");
     if (!f) return nullptr;
     unsigned long long key_size = 0, code_size = 0;
     CodeObject result;
@@ -65,8 +112,9 @@ CodeObject load_from_disk(const std::string &source) {
 }
 
 void store_to_disk(const std::string &source, const std::vector<char> &code) {
-    if (g_cache_dir.empty()) return;
-    const std::string key = cache_key_text(source), path = cache_file(key), tmp = path + ".tmp" + std::to_string((long long)getpid());
+    const std::string dir = cache_dir();
+    if (dir.empty()) return;
+    const std::string key = cache_key_text(source), path = cache_file(dir, key), tmp = path + ".tmp" + std::to_string((long long)getpid());
     std::FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return;   // an unwritable cache directory only costs the next process a compile
     const unsigned long long key_size = key.size(), code_size = code.size();
@@ -120,9 +168,45 @@ void SceneModule::unload() {
     *this = SceneModule();
 }
 
+// ---- small keyed blobs beside the code objects (tile orders) ------------------------------------
+
+bool load_cached_blob(const std::string &kind, const std::string &key, std::vector<uint32_t> &words) {
+    const std::string dir = cache_dir();
+    if (dir.empty()) return false;
+    std::FILE *f = std::fopen(cache_file(dir, kind + key).c_str(), "rb");
+    if (!f) return false;
+    unsigned long long key_size = 0, n_words = 0;
+    bool ok = std::fread(&key_size, sizeof key_size, 1, f) == 1 && std::fread(&n_words, sizeof n_words, 1, f) == 1 &&
+              key_size == kind.size() + key.size() && n_words < (1ull << 28);
+    if (ok) {
+        std::string stored(key_size, '\0');
+        words.resize(n_words);
+        ok = std::fread(&stored[0], 1, key_size, f) == key_size && stored == kind + key &&
+             (n_words == 0 || std::fread(words.data(), sizeof(uint32_t), n_words, f) == n_words);
+    }
+    std::fclose(f);
+    return ok;
+}
+
+void store_cached_blob(const std::string &kind, const std::string &key, const std::vector<uint32_t> &words) {
+    const std::string dir = cache_dir();
+    if (dir.empty()) return;
+    const std::string full = kind + key, path = cache_file(dir, full), tmp = path + ".tmp" + std::to_string((long long)getpid());
+    std::FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const unsigned long long key_size = full.size(), n_words = words.size();
+    const bool ok = std::fwrite(&key_size, sizeof key_size, 1, f) == 1 && std::fwrite(&n_words, sizeof n_words, 1, f) == 1 &&
+                    std::fwrite(full.data(), 1, full.size(), f) == full.size() &&
+                    (words.empty() || std::fwrite(words.data(), sizeof(uint32_t), words.size(), f) == words.size());
+    std::fclose(f);
+    if (ok) std::rename(tmp.c_str(), path.c_str());
+    else std::remove(tmp.c_str());
+}
+
 void set_kernel_cache_dir(const char *dir) {
     std::lock_guard<std::mutex> hold(g_cache_lock);
     g_cache_dir = dir ? dir : "";
+    g_cache_dir_chosen = true;
 }
 
 bool check_scene_source(const std::string &source, std::string &log) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "device_scene.h"
 
@@ -32,9 +33,15 @@ struct SceneModule {
 // Returns false and fills `log` on failure.
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
 
-// Second-level cache of code objects on disk (null or "": none, the default).  Files are keyed by the
-// generated source and the device headers, written atomically, and verified against the full key on load.
+// Second-level cache of code objects on disk.  Default: $RM_KERNEL_CACHE_DIR ("" or "off": none), else the first of
+// $XDG_CACHE_HOME/raymarch_hip, $HOME/.cache/raymarch_hip, /tmp/raymarch_hip-<uid> that is (or can be made) a directory
+// of the calling user's that nobody else can write; set_kernel_cache_dir overrides (null or "": none).  Files are keyed
+// by the generated source and the device headers, written atomically, and verified against the full key on load.
 void set_kernel_cache_dir(const char *dir);
+
+// Small keyed blobs kept in the same directory (tile launch orders): false / no-op without a cache directory.
+bool load_cached_blob(const std::string &kind, const std::string &key, std::vector<uint32_t> &words);
+void store_cached_blob(const std::string &kind, const std::string &key, const std::vector<uint32_t> &words);
 
 // The compile step alone (no device needed): true if `source` compiles for gfx950.
 bool check_scene_source(const std::string &source, std::string &log);

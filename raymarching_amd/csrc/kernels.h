@@ -27,4 +27,8 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sampl
 hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                            uint32_t *prim, float *sd_march, hipStream_t stream);
 
+// Loads this library's ahead-of-time code object on the current device (the runtime would do it at the first launch,
+// inside the first frame).
+hipError_t preload_kernels();
+
 }  // namespace rmdev

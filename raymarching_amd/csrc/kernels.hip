@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
 
 }  // namespace
 
+hipError_t preload_kernels() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&resolve_kernel));
+}
+
 size_t sample_texels(const FrameView &fr) {
     return (size_t)fr.band_count * fr.band_rows * fr.kernel * (size_t)fr.width * fr.kernel;
 }

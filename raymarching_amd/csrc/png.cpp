@@ -51,7 +51,8 @@ bool write_chunk(FILE *f, const char tag[4], const std::vector<uint8_t> &payload
 
 }  // namespace
 
-extern "C" int rm_write_png(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height) {
+// the C entry point (api.cpp: rm_write_png) adds the error text
+int rm_write_png_file(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height) {
     if (!path || !rgba || width == 0 || height == 0) return RM_ERR_INVALID;
     if (!crc_ready) crc_init();
 

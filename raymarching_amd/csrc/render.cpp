@@ -21,6 +21,20 @@ namespace {
 rm_context *g_ctx = nullptr;
 bool g_ok = true;
 std::string g_error;
+// The caller's image buffer, page-locked the first time GPU() sees it so that the read-back is a copy-engine
+// transfer instead of a staged one (the reference's caller allocates the buffer once and reuses it, main.cpp:56).
+void *g_pinned = nullptr;
+
+void unpin() {
+    if (g_pinned) (void)rm_host_unregister(g_pinned);
+    g_pinned = nullptr;
+}
+
+void pin(void *image, size_t bytes) {
+    if (image == g_pinned) return;
+    unpin();
+    if (rm_host_register(image, bytes) == RM_OK) g_pinned = image;   // a buffer that cannot be locked still works, more slowly
+}
 
 void report(int rc, const char *what) {
     g_ok = (rc == RM_OK);
@@ -58,9 +72,12 @@ void setup::shaders(void) {
     push();
 }
 
-// Device buffers are sized by push() and GPU(); nothing to pre-allocate.
+// Where the reference creates its texture and SSBOs (render.cpp:439-445): sizes the device buffers of a frame.
 void setup::buffers(void) {
-    have_context("setup::buffers");
+    if (!have_context("setup::buffers")) return;
+    int rc = rm_set_params(g_ctx, &constants::params);
+    if (rc == RM_OK) rc = rm_reserve(g_ctx);
+    report(rc, "Failed to allocate buffers");
 }
 
 void push(void) {
@@ -77,15 +94,18 @@ void push(void) {
 
 void GPU(unsigned char *image) {
     if (!have_context("GPU")) return;
+    if (image) pin(image, (size_t)constants::params.width * constants::params.height * 4);
     report(rm_render_rgba8(g_ctx, image), "Failed to render");
 }
 
 void GPU(float *image) {
     if (!have_context("GPU")) return;
+    if (image) pin(image, (size_t)constants::params.width * constants::params.height * 4 * sizeof(float));
     report(rm_render_f32(g_ctx, image), "Failed to render");
 }
 
 void destroy(void) {
+    unpin();
     if (g_ctx) rm_destroy(g_ctx);
     g_ctx = nullptr;
     g_ok = true;

@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The library keeps compiled kernels and measured tile orders in a cache directory (default: under the user's home):
+# the tests get a directory of their own, so that what an earlier run left behind cannot change what they observe.
+import tempfile  # noqa: E402
+os.environ["RM_KERNEL_CACHE_DIR"] = tempfile.mkdtemp(prefix="rm_test_cache_")
+
 SCENES = os.path.join(ROOT, "scenes")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -20,7 +20,7 @@ def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
 def test_counting_variant_and_compile_errors(rm):
     scene = rm.Scene(scene_path("menger2.txt"))
     counted = rm.kernel_source(scene, counting=True)
-    assert "trace_body<CompiledScene, 1, true," in counted
+    assert "trace_body<CompiledScene, 1, true>" in counted
     rm.kernel_source_compiles(counted)
     with pytest.raises(rm.RaymarchError) as e:
         rm.kernel_source_compiles(counted.replace("single_sd<", "no_such_function<", 1))

@@ -50,6 +50,28 @@ def test_static_scratch_render_equals_allocating_render(rm, mode):
         r.close()
 
 
+def test_static_scratch_too_small_falls_back_to_pixels_from_the_trace_kernel(rm):
+    """SSAA 3 on a frame whose sample image (78 MB) exceeds the scratch: the scene's own kernel then runs 3 x 3-wave
+    workgroups that hold whole pixels and needs no sample image at all."""
+    r = rm.Renderer(0)
+    try:
+        r.set_scene(rm.Scene(scene_path("default.txt")))
+        p = rm.default_params(width=1200, height=900, kernel=3)
+        assert p.width * p.height * 9 * 8 > rm.lib().rm_static_scratch_bytes()
+        r.set_params(p)
+        got = _frame(r, rm, p, True)
+        assert r.counters()["resolve_ms"] < 0.01           # no resolve kernel ran
+        want = _frame(r, rm, p, False)
+        assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()
+        p = rm.default_params(width=1200, height=900, kernel=6)
+        r.set_params(p)
+        got = _frame(r, rm, p, True)
+        want = _frame(r, rm, p, False)
+        assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()
+    finally:
+        r.close()
+
+
 def test_static_scratch_limits_are_reported(rm):
     r = rm.Renderer(0)
     try:

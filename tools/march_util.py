@@ -3,7 +3,8 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 import raymarching_amd as rm
-from bench import WORKLOADS, ROOT
+from tools.workloads import WORKLOADS
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 for name in sys.argv[1:] or ["default"]:
     scene_name, kw, _ = WORKLOADS[name]
