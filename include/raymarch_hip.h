@@ -109,7 +109,8 @@ typedef struct rm_counters {
     uint64_t probe[16];    /* diagnostic (counting renders of compiled kernels): lane occupancy of code regions as
                               pairs (lanes that executed region r x weight, 64 x weight per wave that went through it):
                               r = 0..3 lattice level 0, 1, 2, deeper (weight 1 per visit); 4 lattice row cells (weight =
-                              cells of the row); 5 gradient taps (lanes whose sample is shaded); 7 scene SDF calls of the
+                              cells of the row); 5 gradient taps (lanes whose sample is shaded); 6: not a pair -- hull tests and rows folded by
+                              clustered runs, per wave; 7 scene SDF calls of the
                               march loop */
 } rm_counters;
 

@@ -61,7 +61,7 @@ __host__ __device__ inline uint32_t lds_bytes(const SceneView &sc) {
 // Region r books, per wave that executes it, (lanes executing it) x weight into probe[2r] and 64 x weight into
 // probe[2r + 1]: their ratio is the region's lane utilisation, weight = the region's cost in instructions or cells.
 constexpr int kProbeLevel0 = 0, kProbeLevel1 = 1, kProbeLevel2 = 2, kProbeLevelDeep = 3, kProbeRowCells = 4, kProbeGradTap = 5,
-              kProbeColourPass = 6, kProbeSceneCall = 7;
+              kProbeClusteredRuns = 6, kProbeSceneCall = 7;
 
 __device__ __forceinline__ unsigned long long *probe_words() {
     __shared__ unsigned long long words[16];
@@ -318,45 +318,125 @@ __device__ __forceinline__ float capped(float acc, float cap) {
     return NEG ? acc : __builtin_fminf(acc, cap);
 }
 
-// One listing: rows [base, base + count), then a hull per 8 rows, then (long runs) a hull per 8 hulls.
-// DIR < 0: hulls of the run's own kind; DIR = 0..2: flat bar hulls.
+// One LDS word per wave, for the exchanges among the lanes of a wave that are executing (a ballot tells who
+// is there, but a value can only be gathered from lanes that are: float max / min atomics on this word).
+__device__ __forceinline__ float *wave_slot() {
+    __shared__ float slots[16];   // workgroups have up to 9 waves
+    return &slots[threadIdx.x >> 6];
+}
+
+// Largest v among the executing lanes (NaNs must have been replaced by the caller).  Every lane performs the same
+// three LDS operations in program order.
+__device__ __forceinline__ float wave_max_of_executing(float v) {
+    float *slot = wave_slot();
+    __hip_atomic_store(slot, -__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The executing lanes' points, enclosed: the first such lane's point and the largest distance (1-norm, which is
+// at least the Euclidean and the maximum norm) of any of them from it.  Wave-uniform.
+struct WaveBall {
+    V3 centre;
+    float reach;
+};
+
+template <int NP>
+__device__ __forceinline__ WaveBall wave_ball(const V3 (&p)[NP]) {
+    const int first = __builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+    WaveBall ball;
+    ball.centre = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0].x), first)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0].y), first)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0].z), first)));
+    float spread = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float d = __builtin_fabsf(p[n].x - ball.centre.x) + __builtin_fabsf(p[n].y - ball.centre.y) + __builtin_fabsf(p[n].z - ball.centre.z);
+        spread = d <= spread ? spread : d;   // a NaN distance stays (and then reaches everything)
+    }
+    ball.reach = wave_max_of_executing(spread == spread ? spread : __builtin_inff());
+    return ball;
+}
+
+// Distance of a hull row from a point, as the hull tests above compute it (a lower bound of its rows' distances).
+template <uint32_t KIND, int DIR>
+__device__ __forceinline__ float hull_value(const RowWords ra, const RowWords rb, V3 c) {
+    if (DIR >= 0) {
+        const float pa_ = DIR == 2 ? c.y : c.x, pb_ = DIR == 0 ? c.y : c.z;
+        return __builtin_fmaxf(__builtin_fabsf(pa_ - ra[0]) - ra[2], __builtin_fabsf(pb_ - ra[1]) - ra[3]);
+    }
+    if (KIND == K_SPHERE) return __builtin_sqrtf(sphere_d2(c, ra[0], ra[1], ra[2])) * 0.999999f - ra[3];
+    const float dx = __builtin_fabsf(c.x - ra[0]) - ra[3];
+    const float dy = __builtin_fabsf(c.y - ra[1]) - rb[0];
+    const float dz = __builtin_fabsf(c.z - ra[2]) - rb[1];
+    return __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz);
+}
+
+// What a row's distance must stay below to change some executing lane's accumulator: the largest `need` of the
+// wave's points (+inf if one of them is a NaN).
+template <bool NEG, int NP>
+__device__ __forceinline__ float listing_need(const float (&acc)[NP], const float (&cap)[NP]) {
+    float need = -__builtin_inff();
+    bool unordered = false;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float c = capped<NEG>(acc[n], cap[n]);
+        const float mine = NEG ? -c : c;
+        unordered = unordered || mine != mine;
+        need = __builtin_fmaxf(need, mine);
+    }
+    return wave_max_of_executing(unordered ? __builtin_inff() : need);
+}
+
+// One listing: rows [base, base + count), then a hull per kClusterSize rows.  DIR < 0: hulls of the run's own kind; DIR = 0..2: flat bar hulls.
+//
+// Broad phase, once per wave instead of once per lane: the hulls are dealt out to the lanes, 64 at a time, and each
+// lane tests ITS hull against the ball around all of the wave's points -- hull distances are 1-Lipschitz, so at
+// every point of the wave a hull is worth at least its distance from the ball's centre minus the ball's reach, and
+// a hull whose bound is not below the largest `need` of the wave (need = what a row's distance must stay below to
+// change that lane's accumulator) is ruled out for every lane.  The survivors (a ballot) are then tested lane by
+// lane with the exact test and, where some lane needs them, have their rows folded with the plain formula, so the
+// fold's result is that of visiting every row, bit for bit.  Margins: 1e-5 of the reach for its own roundings,
+// eps (at the centre) for the hull distance's, as in the per-lane test.
 template <uint32_t KIND, int DIR, bool NEG, bool MAX, int NP>
-__device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_t base, uint32_t count, bool has_supers,
+__device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_t base, uint32_t count, const WaveBall &ball, float centre_eps,
                                              const V3 (&p)[NP], float (&acc)[NP], const float (&cap)[NP], const float (&eps)[NP],
                                              uint32_t &tested, uint32_t &evaluated) {
     uint32_t no_prim[NP];
 #pragma unroll
     for (int n = 0; n < NP; ++n) no_prim[n] = kNoPrim;
     const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
-    const uint32_t n_supers = has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 1u;
-    const uint32_t cfirst = base + count, sfirst = cfirst + n_clusters;
-    for (uint32_t s = 0; s < n_supers; ++s) {
-        uint32_t c0 = 0, c1 = n_clusters;
-        if (has_supers) {
-            const RowWords ha = pa[sfirst + s];
-            RowWords hb = ha;
-            if (DIR < 0) hb = pb[sfirst + s];
-            bool need = false;
+    const uint32_t cfirst = base + count;
+    // the hulls are dealt to the lanes that are executing (lanes whose ray has ended are not here to test theirs)
+    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_here = (uint32_t)__builtin_popcountll(here);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+    const float wave_need = listing_need<NEG, NP>(acc, cap);
+    const float bound_slack = ball.reach * 1.00001f + centre_eps;
+    for (uint32_t g0 = 0; g0 < n_clusters; g0 += n_here) {
+        const uint32_t g = g0 + rank;
+        const bool mine = g < n_clusters;
+        const RowWords ha = pa[cfirst + (mine ? g : 0u)];
+        RowWords hb = ha;
+        if (DIR < 0 && KIND != K_SPHERE) hb = pb[cfirst + (mine ? g : 0u)];
+        float bound = hull_value<KIND, DIR>(ha, hb, ball.centre) - bound_slack;
+        bound = bound == bound ? bound : -__builtin_inff();   // a hull that cannot be placed is visited, first
+        unsigned long long survivors = __builtin_amdgcn_ballot_w64(mine && !(bound >= wave_need));
+        tested++;
+        for (; survivors != 0ull; survivors &= survivors - 1ull) {
+            // the surviving lane's rank among the executing lanes is its hull's place in this round
+            const unsigned long long below = (survivors & (0ull - survivors)) - 1ull;
+            const uint32_t c = g0 + (uint32_t)__builtin_popcountll(here & below);
+            const RowWords ca = pa[cfirst + c];
+            RowWords cb = ca;
+            if (DIR < 0) cb = pb[cfirst + c];
+            bool wanted = false;
 #pragma unroll
             for (int n = 0; n < NP; ++n)
-                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], capped<NEG>(acc[n], cap[n]), eps[n])
-                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], capped<NEG>(acc[n], cap[n]), eps[n]));
+                wanted = wanted || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ca, cb, p[n], capped<NEG>(acc[n], cap[n]), eps[n])
+                                            : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ca, p[n], capped<NEG>(acc[n], cap[n]), eps[n]));
             tested++;
-            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
-            c0 = s * kClusterSize;
-            c1 = c0 + kClusterSize < n_clusters ? c0 + kClusterSize : n_clusters;
-        }
-        for (uint32_t c = c0; c < c1; ++c) {
-            const RowWords ha = pa[cfirst + c];
-            RowWords hb = ha;
-            if (DIR < 0) hb = pb[cfirst + c];
-            bool need = false;
-#pragma unroll
-            for (int n = 0; n < NP; ++n)
-                need = need || (DIR < 0 ? hull_needs_rows<KIND, NEG>(ha, hb, p[n], capped<NEG>(acc[n], cap[n]), eps[n])
-                                        : bar_hull_needs_rows<(DIR < 0 ? 0 : DIR), NEG>(ha, p[n], capped<NEG>(acc[n], cap[n]), eps[n]));
-            tested++;
-            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+            if (__builtin_amdgcn_ballot_w64(wanted) == 0) continue;
             const uint32_t i0 = c * kClusterSize;
             const uint32_t rows = i0 + kClusterSize < count ? kClusterSize : count - i0;
             fold_run<KIND, NEG, MAX, NP, false>(pa, pb, (ConstIndex)0, base + i0, rows, p, acc, no_prim);
@@ -375,16 +455,23 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
     for (int n = 0; n < NP; ++n)
         eps[n] = 2e-6f * (__builtin_fabsf(p[n].x) + __builtin_fabsf(p[n].y) + __builtin_fabsf(p[n].z) + magnitude);
     uint32_t tested = 0, evaluated = 0;
+    const WaveBall ball = wave_ball<NP>(p);
+    const float centre_eps = 2e-6f * (__builtin_fabsf(ball.centre.x) + __builtin_fabsf(ball.centre.y) + __builtin_fabsf(ball.centre.z) + magnitude);
     if (KIND == K_CROSS || KIND == K_CROSS_ISO) {
         const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
         const uint32_t stride = count + n_clusters + (has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 0u);
-        fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, cap, eps, tested, evaluated);
-        fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, has_supers, p, acc, cap, eps, tested, evaluated);
-        fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, has_supers, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
     } else {
-        fold_listing<KIND, -1, NEG, MAX, NP>(pa, pb, first, count, has_supers, p, acc, cap, eps, tested, evaluated);
+        fold_listing<KIND, -1, NEG, MAX, NP>(pa, pb, first, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
     }
     if (COUNT) {
+        // per wave: hull tests (dealt rounds and survivors' exact tests) and rows folded
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+            atomicAdd(&probe_words()[2 * kProbeClusteredRuns], (unsigned long long)tested);
+            atomicAdd(&probe_words()[2 * kProbeClusteredRuns + 1], (unsigned long long)evaluated);
+        }
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
             work[n].evals += tested + evaluated;
@@ -481,10 +568,6 @@ __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONE
 // word per wave (a float max is exact and order-free, so the row's result does not depend on who
 // evaluated which cell).  Must be called from control flow that is uniform among the executing
 // lanes; lanes that have left the walk earlier simply are not among the workers.
-__device__ __forceinline__ float *wave_slot() {
-    __shared__ float slots[16];   // workgroups have up to 9 waves
-    return &slots[threadIdx.x >> 6];
-}
 
 template <int AXIS, bool COUNT = false>
 __device__ __forceinline__ float lattice_rows(bool active, const float *T, const uint32_t *ONES, int n, float pt, float h, float d1,

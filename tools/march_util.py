@@ -22,6 +22,7 @@ for name in sys.argv[1:] or ["default"]:
     c = r.counters()
     print(json.dumps({"workload": name, "kernel_ms": round(ms, 4), "march_util": round(c["march_steps"] / max(1, c["march_slots"]), 4),
                       "regions(lanes/slots)": {n: (round(c["probe"][2 * i] / max(1, c["probe"][2 * i + 1]), 3), c["probe"][2 * i + 1] // 64)
-                                               for i, n in enumerate(["level0", "level1", "level2", "deeper", "row_cells", "grad_taps", "colour", "scene_calls"])},
+                                               for i, n in enumerate(["level0", "level1", "level2", "deeper", "row_cells", "grad_taps", "-", "scene_calls"])},
+                      "clustered_runs_per_wave(hull tests, rows folded)": c["probe"][12:14],
                       **{k: c[k] for k in ("sdf_calls", "march_steps", "march_slots", "rays", "prim_evals", "flops_executed")}}))
     r.close()
