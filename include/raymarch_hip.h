@@ -295,6 +295,20 @@ typedef enum rm_shading { RM_SHADE_ALL = 0, RM_SHADE_COLOURED = 1 } rm_shading;
 int rm_set_shading(rm_context *ctx, int mode);
 
 /*
+ * Lane refill (no counterpart in the reference, whose compute shader runs a pixel's samples and rays one after the
+ * other in one invocation, shader.comp:353-365; the frame is the same either way).  Off by default.  When on, the
+ * scene's own kernels (RM_KERNEL_COMPILED; takes effect at the next rm_set_scene) give every wave a tile of
+ * 2^tile_w_log2 x 2^tile_h_log2 samples (3..8 each), and a lane whose ray has ended goes on at once -- with its
+ * sample's gradient taps, its next shadow ray, or the tile's next sample -- instead of waiting for the slowest of
+ * the wave's 64 rays; surface colours are found 64 at a time from a queue in LDS.  Measured on MI355X this keeps
+ * 95 % of the march loop's lanes busy (88 % without) and is slower all the same, 0.92-0.99 ms against 0.58 ms per
+ * shipped frame: lanes of one wave at different stages of their samples share less of the evaluator's wave-wide
+ * culling, and every turn of the loop runs some lane's change of stage with most lanes masked off.  Kept for study
+ * and as the measured answer; SSAA samples go through the resolve kernel in this mode.  0, 0 turns it off.
+ */
+int rm_set_lane_refill(rm_context *ctx, uint32_t tile_w_log2, uint32_t tile_h_log2);
+
+/*
  * The compiled mode's two steps without a device or a context (build checks, inspection):
  *   rm_kernel_source           writes the HIP source rm_set_scene would generate for the scene into
  *                              `buffer` (NUL-terminated, truncated to `capacity`) and its full length,

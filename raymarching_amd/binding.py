@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_reserve", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
 )
@@ -100,6 +100,7 @@ def lib():
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
     L.rm_set_shading.argtypes = [vp, C.c_int]
+    L.rm_set_lane_refill.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.rm_get_tile_costs.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rm_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rm_stream.argtypes = [vp]
@@ -303,6 +304,11 @@ class Renderer:
         with the lighting is zero) and shadow rays stop once past their light; False: every sample and ray
         does the reference's full work."""
         _check(lib().rm_set_shading(self._h, 1 if coloured_only else 0), "rm_set_shading")
+
+    def set_lane_refill(self, tile_w_log2, tile_h_log2):
+        """Tiles of 2^w x 2^h samples whose lanes take the next piece of work when their ray has ended (0, 0: off, the
+        default; measured slower).  Applies to the next set_scene."""
+        _check(lib().rm_set_lane_refill(self._h, tile_w_log2, tile_h_log2), "rm_set_lane_refill")
 
     def tile_costs(self):
         """[tiles_y, tiles_x] uint32 durations (10 ns ticks) of the last render that timed its tiles."""

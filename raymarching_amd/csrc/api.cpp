@@ -153,6 +153,9 @@ struct rm_context {
         uint32_t waves_per_side;   // tile shape of the launch
     };
     int tile_scheduling = RM_TILES_BY_COST;
+    // rm_set_lane_refill; the environment's RM_REFILL=WH (two digits, e.g. 44) presets it, for the profiling tools
+    uint32_t refill_w_log2 = std::getenv("RM_REFILL") ? (uint32_t)(std::atoi(std::getenv("RM_REFILL")) / 10) : 0u;
+    uint32_t refill_h_log2 = std::getenv("RM_REFILL") ? (uint32_t)(std::atoi(std::getenv("RM_REFILL")) % 10) : 0u;
     int shading = RM_SHADE_COLOURED;
     uint64_t scene_serial = 0;
     std::string scene_fingerprint;   // bytes that identify the uploaded scene, camera and lights (keys cached tile orders)
@@ -281,6 +284,14 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             fused = true;
         }
     }
+    const bool refill = compiled && ctx->refill_w_log2 >= 3u && ctx->refill_h_log2 >= 3u && ctx->module.trace_refill != nullptr &&
+                        fr.iterations > 0 && !static_samples;
+    if (refill) {
+        fused = false;
+        n_side = 1u;
+        fr.refill_w_log2 = ctx->refill_w_log2;
+        fr.refill_h_log2 = ctx->refill_h_log2;
+    }
     if (fused) {
         fr.pixels_f32 = d_f32;
         fr.pixels_rgba8 = d_rgba8;
@@ -303,6 +314,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
     const uint32_t side = 8u * n_side;
     pend.n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
+    if (refill) pend.n_tiles = (size_t)((sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2) * ((sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2);
     if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
         rm_context::OrderKey key{};
         key.params = ctx->params;
@@ -312,7 +324,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         key.points_per_lane = pts;
         key.shading = (uint32_t)ctx->shading;
         key.fused = fused ? 1u : 0u;
-        key.waves_per_side = n_side;
+        key.waves_per_side = refill ? 100u + 16u * fr.refill_w_log2 + fr.refill_h_log2 : n_side;
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
             fr.extra_slots = ctx->order_extra;
@@ -325,10 +337,10 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             ctx->order_key = key;
             ctx->order_ready = false;
             pend.measuring = true;
-            ctx->measured_tiles_x = (sw + side * pts - 1u) / (side * pts);
-            ctx->measured_tiles_y = (sh + side - 1u) / side;
+            ctx->measured_tiles_x = refill ? (sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2 : (sw + side * pts - 1u) / (side * pts);
+            ctx->measured_tiles_y = refill ? (sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2 : (sh + side - 1u) / side;
             RM_HIP(ctx->d_tile_cost.reserve(pend.n_tiles));
-            pend.splittable = compiled && pts == 1u;
+            pend.splittable = compiled && pts == 1u && !refill;
             pend.part_multiple = fused ? fr.kernel : 1u;
             pend.tile_side = side;
             RM_HIP(ctx->d_tile_order.reserve(pend.n_tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
@@ -345,7 +357,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     }
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true), kCompiledPts,
+        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true, ctx->refill_w_log2 != 0u), kCompiledPts,
                                          ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
@@ -606,7 +618,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     ctx->counting_module.unload();
     if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
         std::string log;
-        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false);
+        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false, ctx->refill_w_log2 != 0u);
         if (!rmdev::compile_scene_module(source, kCompiledPts, ctx->module, log)) {
             ctx->have_scene = false;
             return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
@@ -775,7 +787,7 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
     std::string why;
     rmdev::HostProgram prog;
     if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_kernel_source: " + why);
-    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, counting != 0);
+    const std::string src = rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, counting != 0, std::getenv("RM_REFILL") != nullptr);
     *length = src.size();
     if (buffer && capacity) {
         const size_t n = src.size() < capacity - 1 ? src.size() : capacity - 1;
@@ -817,6 +829,16 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode) {
     if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
     ctx->tile_scheduling = mode;
     ctx->order_ready = false;
+    return RM_OK;
+}
+
+int rm_set_lane_refill(rm_context *ctx, uint32_t tile_w_log2, uint32_t tile_h_log2) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    const bool off = tile_w_log2 == 0u && tile_h_log2 == 0u;
+    if (!off && (tile_w_log2 < 3u || tile_h_log2 < 3u || tile_w_log2 > 8u || tile_h_log2 > 8u))
+        return fail(RM_ERR_INVALID, "rm_set_lane_refill: tile sides are 2^3 .. 2^8 samples (0, 0 turns it off)");
+    ctx->refill_w_log2 = tile_w_log2;
+    ctx->refill_h_log2 = tile_h_log2;
     return RM_OK;
 }
 

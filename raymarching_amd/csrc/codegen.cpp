@@ -95,6 +95,20 @@ struct Emitter {
         evals = flops = 0;
     }
 
+    // A root child whose value decides, where it is the scene's, that the surface has no colour: a box or cross of colour
+    // (0, 0, 0) folded into a union's minimum, with no coloured primitive before it in depth-first order (of equal
+    // distances the earlier primitive's colour wins, so a tie between such a child and anything coloured is the child's).
+    bool wall_candidate(const Rec &r) const {
+        const uint32_t code = r.flags & 15u;
+        if ((code != REC_BOX && code != REC_CROSS) || (r.flags & FOLD_MAX) != 0u || !(prog.root_identity > 0)) return false;
+        for (uint32_t i = 0; i <= r.prim && i < prog.colors.size(); i++) {
+            const Float4 &c = prog.colors[i];
+            if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f) return false;
+        }
+        return true;
+    }
+    bool any_wall = false;
+
     std::string acc(uint32_t d) const { return "a" + std::to_string(d); }
     std::string accp(uint32_t d) const { return track ? "q" + std::to_string(d) : "no_prim"; }
 
@@ -113,7 +127,16 @@ struct Emitter {
     void leaf(const Rec &r, uint32_t depth) {
         const uint32_t code = r.flags & 15u;
         const bool neg = (r.flags & FOLD_NEG) != 0, mx = (r.flags & FOLD_MAX) != 0;
-        if (code <= REC_CROSS) {
+        if (code <= REC_CROSS && !track && depth == 0 && wall_candidate(r)) {
+            // min(acc, +-v) as single_sd folds it, with the value kept: see `wall` in emit_body
+            std::snprintf(buf, sizeof buf,
+                          "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { const float v = %ssingle_distance<%s>(p[n], %s); "
+                          "a0[n] = __builtin_fminf(a0[n], v); wall[n] = __builtin_fminf(wall[n], v); }\n",
+                          neg ? "-" : "", code_name(code), centre_and_half(r).c_str());
+            evals += 1;
+            flops += flops_of_code(code);
+            any_wall = true;
+        } else if (code <= REC_CROSS) {
             if (track) {
                 std::snprintf(buf, sizeof buf, "    single_surface<%s, %uu, NP>(p, %s, %s, %s, %uu);\n", code_name(code),
                               r.flags & (FOLD_NEG | FOLD_MAX), acc(depth).c_str(), accp(depth).c_str(), centre_and_half(r).c_str(), r.prim);
@@ -277,37 +300,46 @@ struct Emitter {
 
 // body of sd() (track = false) or surface() (track = true)
 std::string emit_body(const HostProgram &prog, bool track) {
-    Emitter e{ prog, track, std::string(), 0, 0, { 0 } };
+    Emitter e{ prog, track, std::string(), 0, 0, { 0 }, false };
     std::vector<Item> top;
     parse_children(prog.recs, 0, top);
     e.declare(0, prog.root_identity);
-    if (!track) e.s += "    uint32_t no_prim[NP];\n    float no_cap[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { no_prim[n] = kNoPrim; no_cap[n] = __builtin_inff(); }\n    (void)cap;\n";
+    // wall: the smallest value among the root's colourless leading boxes (see wall_candidate); where it is the scene's
+    // value the surface there is colourless, known without the colour-tracking walk
+    if (!track) e.s += "    uint32_t no_prim[NP];\n    float no_cap[NP], wall[NP];\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { no_prim[n] = kNoPrim; no_cap[n] = __builtin_inff(); wall[n] = __builtin_inff(); }\n    (void)cap;\n";
     else e.s += "    uint32_t evals_unused[NP] = {};\n";
     e.children(top, 0);
-    e.s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : "") + " }\n";
+    e.s += "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) { out_sd[n] = a0[n];" + std::string(track ? " out_prim[n] = q0[n];" : (e.any_wall ? " colourless[n] = wall[n] == a0[n];" : " colourless[n] = false;")) + " }\n";
     return e.s;
 }
 
 }  // namespace
 
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting) {
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting, bool refill) {
     std::string s;
-    s += "#include \"trace_kernel.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
+    s += "#include \"trace_refill.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
-         "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP]) {\n";
+         "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {\n";
     s += emit_body(prog, false);
     s += "}\n\n";
     s += "template <int NP>\nstatic __device__ __forceinline__ void surface(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
          "                                               float (&out_sd)[NP], uint32_t (&out_prim)[NP]) {\n";
     s += emit_body(prog, true);
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
-    // launched with 1, 4 or 9 waves per workgroup (jit.cpp: launch_trace_module)
-    char buf[512];
+    // rm_trace: launched with 1, 4 or 9 waves per workgroup; rm_trace_refill: one wave (jit.cpp: launch_trace_module)
+    char buf[1024];
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(576, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
                   "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s>(sc, fr, samples, counters);\n}\n\n",
                   min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane, counting ? "true" : "false");
     s += buf;
+    if (refill) {
+        std::snprintf(buf, sizeof buf,
+                      "extern \"C\" __global__ __launch_bounds__(64, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
+                      "        WorkCounters *counters) {\n    trace_refill_body<CompiledScene, %s>(sc, fr, samples, counters);\n}\n\n",
+                      min_waves, counting ? "rm_trace_refill_counting" : "rm_trace_refill", counting ? "true" : "false");
+        s += buf;
+    }
     s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
          "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n";
     return s;

@@ -12,6 +12,7 @@ namespace rmdev {
 // Kernels emitted: rm_trace (points_per_lane samples per lane, register budget for min_waves waves
 // per SIMD, launched with 1, 4 or 9 waves per workgroup, with or without work counting) and
 // rm_eval_sdf; signatures as the kernels of kernels.hip.
-std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting);
+// refill: also rm_trace_refill, the kernel whose lanes take their tile's next sample when their own is finished.
+std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting, bool refill);
 
 }  // namespace rmdev

@@ -169,6 +169,9 @@ struct FrameView {
     // the lighting is zero either way) and shadow rays stop once past their light; zero: every sample and
     // ray does the reference's full work, which is what work counts that are compared with the reference's need.
     uint32_t skip_unlit;
+    // Tile of the kernel whose lanes take the tile's next sample when their own is finished (trace_refill.h):
+    // 2^refill_w_log2 x 2^refill_h_log2 samples, both at least 8.
+    uint32_t refill_w_log2, refill_h_log2;
 };
 
 struct WorkCounters {

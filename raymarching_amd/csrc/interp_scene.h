@@ -22,8 +22,10 @@ namespace rmdev {
 struct InterpretedScene {
     template <int NP, bool COUNT>
     static __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
-                                             Work (&work)[NP], const float (&cap)[NP]) {
+                                             Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {
         (void)cap;   // the record walker does not use the caller's upper bound
+    #pragma unroll
+        for (int n = 0; n < NP; ++n) colourless[n] = false;   // nor does it know a surface's colour before the tracking walk
         float acc[NP];
         uint32_t no_prim[NP];
     #pragma unroll

@@ -256,6 +256,15 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
             return false;
         }
     }
+    if (source.find("rm_trace_refill") != std::string::npos) {
+        const char *name = counting ? "rm_trace_refill_counting" : "rm_trace_refill";
+        e = hipModuleGetFunction(&out.trace_refill, out.module, name);
+        if (e != hipSuccess) {
+            log = std::string("hipModuleGetFunction(") + name + "): " + hipGetErrorString(e);
+            out.unload();
+            return false;
+        }
+    }
     out.points_per_lane = points_per_lane;
     out.compile_seconds = seconds;
     return true;
@@ -270,6 +279,12 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
     SceneView sc_arg = sc;
     FrameView fr_arg = fr;
     void *args[] = { &sc_arg, &fr_arg, &samples, &counters };
+    if (fr.refill_w_log2 != 0u) {
+        // one wave per tile of 2^w x 2^h samples; LDS: the lattice tables and the queue of points awaiting their colour
+        const uint32_t tiles_x = (sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2;
+        const uint32_t tiles_y = (sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2;
+        return hipModuleLaunchKernel(m.trace_refill, tiles_x, tiles_y, 1, 64u, 1, 1, (sc.lattice_words + 4u * 128u) * 4u, stream, args, nullptr);
+    }
     const uint32_t side = 8u * waves_per_side;
     const uint32_t tiles_x = (sw + side * pts - 1u) / (side * pts);
     const uint32_t extra_rows = fr.tile_order ? (fr.extra_slots + tiles_x - 1u) / tiles_x : 0u;

@@ -21,6 +21,7 @@ extern const unsigned kEmbeddedHeaderCount;
 struct SceneModule {
     hipModule_t module = nullptr;
     hipFunction_t trace = nullptr;
+    hipFunction_t trace_refill = nullptr;   // null unless the source holds it
     hipFunction_t eval_sdf = nullptr;
     uint32_t points_per_lane = 0;   // of `trace`
     double compile_seconds = 0.0;   // 0 when the code came from the process-wide cache

@@ -1,6 +1,7 @@
 // trace_kernel.h -- the render kernel body, generic over the scene evaluator `Scene`
 // (InterpretedScene, or the straight-line evaluator generated for one scene):
-//     Scene::sd<NP, COUNT>(sc, lds, points, distances, work, cap)  distance only
+//     Scene::sd<NP, COUNT>(sc, lds, points, distances, work, cap, colourless)  distance only; colourless[n]: the value is
+//                                                                  that of a surface known to have colour (0, 0, 0)
 //     Scene::surface<NP>(sc, lds, points, distances, primitives)   distance + colour-carrying primitive
 #pragma once
 
@@ -47,7 +48,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         if (all_done) break;
         float sd[kPts];
         Work work[kPts] = {};
-        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap);
+        bool colourless_unused[kPts];
+        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap, colourless_unused);
         probe<COUNT>(kProbeSceneCall, 1u);
         if (COUNT) {
             // the wave sits through this iteration with all of its lanes, whichever of them still march (with one
@@ -249,7 +251,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                     float no_cap[kPts];
 #pragma unroll
                     for (int s = 0; s < kPts; ++s) no_cap[s] = __builtin_inff();
-                    Scene::template sd<kPts, COUNT>(sc, lds, q, sd, work, no_cap);
+                    bool colourless_unused[kPts];
+                    Scene::template sd<kPts, COUNT>(sc, lds, q, sd, work, no_cap, colourless_unused);
                     if (COUNT) {
                         bool any_lit = false;
 #pragma unroll
@@ -383,7 +386,8 @@ __device__ __forceinline__ void eval_sdf_body(const SceneView &sc, const float *
         float dm[1];
         Work work[1] = {};
         const float no_cap[1] = { __builtin_inff() };
-        Scene::template sd<1, false>(sc, lds, p, dm, work, no_cap);
+        bool colourless_unused[1];
+        Scene::template sd<1, false>(sc, lds, p, dm, work, no_cap, colourless_unused);
         if (t < n) sd_march[t] = dm[0];
     }
 }

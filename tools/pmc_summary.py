@@ -13,13 +13,16 @@ for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     if not os.path.isfile(path):
         continue
     sums, launches = defaultdict(float), set()
-    for row in csv.DictReader(open(path)):
-        if row["Kernel_Name"] != "rm_trace":
+    rows = list(csv.DictReader(open(path)))
+    # the frame's kernel: rm_trace, or rm_trace_refill when lane refill is on (rm_trace then only ran the one-pixel warm-up launch of rm_set_scene)
+    kernel = "rm_trace_refill" if any(r["Kernel_Name"] == "rm_trace_refill" for r in rows) else "rm_trace"
+    for row in rows:
+        if row["Kernel_Name"] != kernel or (row.get("Grid_Size") or row.get("Grid_Size_X") or "") in ("64",):
             continue
         sums[row["Counter_Name"]] += float(row["Counter_Value"])
         launches.add(row["Dispatch_Id"])
     n = max(1, len(launches))
-    print(f"[{name}] rm_trace launches: {len(launches)}")
+    print(f"[{name}] {kernel} launches: {len(launches)}")
     for k in sorted(sums):
         print(f"  {k:26s} {sums[k]:.6g}")
     if "SQ_THREAD_CYCLES_VALU" in sums and sums.get("SQ_ACTIVE_INST_VALU"):
