@@ -52,3 +52,23 @@ def test_full_frame_record_is_exact():
     assert rec["counters"]["rays"] == 1024 * 768 * 9 * 3
     import hashlib
     assert hashlib.sha256(gold_png().tobytes()).hexdigest() == rec["sha256_rgba8"]
+
+
+def test_the_golden_render_tells_the_oracle_from_its_plausible_variants(oracle):
+    """The pin discriminates: with one operation replaced by another plausible form -- normalize by division, the cross as an exact
+    median, lerp as a weighted sum, fused dot products -- the oracle leaves the reference's committed render (tests/golden/variants.json
+    holds the full-frame counts, from tests/golden/make_variants.py: 61, 14, 128 and 143 of 786 432 pixels), while the forms the oracle
+    uses reproduce every pixel.  Re-rendered here: for each variant a few of the rows that hold its differing pixels."""
+    rec = json.load(open(os.path.join(GOLDEN, "variants.json")))
+    assert set(rec) == {"normalize_by_division", "cross_as_exact_median", "lerp_weighted", "dot_products_fused"}
+    g = gold_png()
+    sc = oracle.Scene(scene_path("default.txt"))
+    for name, v in rec.items():
+        assert v["pixels_off"] > 0, name
+        rows = v["sample_rows"][:2]
+        xy = [(x, y) for y in rows for x in range(1024)]
+        base = oracle.quantize(sc.render_pixels(oracle.default_params(), xy)).reshape(len(rows), 1024, 4)
+        np.testing.assert_array_equal(base, g[rows])
+        wrong = oracle.quantize(sc.render_pixels(oracle.default_params(**v["params"]), xy)).reshape(len(rows), 1024, 4)
+        off = [int((wrong[i] != g[r]).any(axis=1).sum()) for i, r in enumerate(rows)]
+        assert off == v["pixels_off_in_sample_rows"][:2], (name, off)
