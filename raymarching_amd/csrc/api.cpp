@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -141,6 +143,10 @@ struct rm_context {
     DeviceArray<rmdev::WorkCounters> d_counters;
     DeviceArray<float> d_points, d_sd, d_camera;
     DeviceArray<uint32_t> d_prim, d_lattice, d_row_prim;
+    DeviceArray<uint32_t> d_grid_cells, d_grid_entries, d_grid_total;
+    DeviceArray<float> d_grid_bound;
+    double grid_build_ms = 0.0;
+    uint64_t grid_entries = 0, grid_cells = 0;
 
     // Cost-ordered tile launch: the first frame of a configuration (scene, parameters, row bands,
     // kernel shape) measures every tile's duration, later frames start the expensive tiles first.
@@ -462,6 +468,81 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
     return finish_bands(ctx);
 }
 
+// Builds the cell grid over the root's long runs (device_scene.h: GridView) on the device; leaves ctx->scene.grid empty
+// if the scene has no such runs.  The box: around the runs' primitives, an eighth of its longest side wider on every
+// side (camera and shadow rays start and end near the scene); about 256 cells per row, a million at most.
+int build_grid(rm_context *ctx) {
+    rmdev::GridView &g = ctx->scene.grid;
+    g = rmdev::GridView{};
+    ctx->grid_build_ms = 0.0;
+    ctx->grid_entries = ctx->grid_cells = 0;
+    const rmdev::HostProgram &hp = ctx->program;
+    if (hp.grid_runs.empty() || ctx->evaluator != RM_EVAL_LATTICE || ctx->kernel_mode != RM_KERNEL_COMPILED) return RM_OK;
+    rmdev::GridBuild b{};
+    std::vector<rmdev::GridRun> runs = hp.grid_runs;
+    std::stable_sort(runs.begin(), runs.end(), [](const rmdev::GridRun &x, const rmdev::GridRun &y) { return x.cls < y.cls; });
+    size_t n_rows = 0;
+    for (size_t i = 0; i < runs.size(); i++) {
+        b.runs[i] = runs[i];
+        n_rows += runs[i].count;
+    }
+    b.n_runs = (uint32_t)runs.size();
+    double side[3], longest = 0.0;
+    for (int k = 0; k < 3; k++) {
+        side[k] = (double)hp.grid_hi[k] - (double)hp.grid_lo[k];
+        if (!(side[k] >= 0.0) || !std::isfinite(side[k])) return RM_OK;   // no box to speak of: the hull walk serves
+        longest = std::max(longest, side[k]);
+    }
+    if (!(longest > 0.0)) return RM_OK;
+    const double pad = 0.125 * longest;
+    double volume = 1.0;
+    for (int k = 0; k < 3; k++) {
+        side[k] += 2.0 * pad;
+        volume *= side[k];
+    }
+    const double target = std::min(1048576.0, std::max(4096.0, 256.0 * (double)n_rows));
+    const double cell = std::cbrt(volume / target);
+    if (!(cell > 0.0) || !std::isfinite(cell)) return RM_OK;
+    uint64_t n_cells = 1;
+    for (int k = 0; k < 3; k++) {
+        b.origin[k] = (float)((double)hp.grid_lo[k] - pad);
+        b.dims[k] = (uint32_t)std::min(1024.0, std::max(1.0, std::ceil(side[k] / cell)));
+        n_cells *= b.dims[k];
+    }
+    b.cell = (float)cell;
+    const auto t0 = std::chrono::steady_clock::now();
+    RM_HIP(ctx->d_grid_cells.reserve(n_cells * 4));
+    RM_HIP(ctx->d_grid_bound.reserve(n_cells));
+    RM_HIP(ctx->d_grid_total.reserve(1));
+    b.pa = ctx->d_pa.ptr;
+    b.pb = ctx->d_pb.ptr;
+    b.cells = ctx->d_grid_cells.ptr;
+    b.bound = ctx->d_grid_bound.ptr;
+    b.total = ctx->d_grid_total.ptr;
+    RM_HIP(hipMemsetAsync(b.total, 0, sizeof(uint32_t), ctx->stream));
+    RM_HIP(rmdev::launch_count_grid(b, ctx->stream));
+    uint32_t total = 0;
+    RM_HIP(hipMemcpyAsync(&total, b.total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((uint64_t)total > (1ull << 28)) return RM_OK;   // a gigabyte of lists: leave such a scene to the hull walk
+    RM_HIP(ctx->d_grid_entries.reserve(total));
+    b.entries = ctx->d_grid_entries.ptr;
+    RM_HIP(rmdev::launch_fill_grid(b, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    g.cells = b.cells;
+    g.entries = b.entries;
+    for (int k = 0; k < 3; k++) {
+        g.origin[k] = b.origin[k];
+        g.dims[k] = b.dims[k];
+    }
+    g.cell = b.cell;
+    g.inv_cell = 1.0f / b.cell;
+    ctx->grid_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->grid_entries = total;
+    ctx->grid_cells = n_cells;
+    return RM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -507,6 +588,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->module.unload();
     ctx->counting_module.unload();
     ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release(); ctx->h_tiles.release();
+    ctx->d_grid_cells.release(); ctx->d_grid_entries.release(); ctx->d_grid_total.release(); ctx->d_grid_bound.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -598,6 +680,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.lattice = ctx->d_lattice.ptr;
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;
+    if (int rc = build_grid(ctx)) return rc;
     ctx->scene_serial++;
     {
         std::string &fp = ctx->scene_fingerprint;

@@ -213,6 +213,19 @@ struct Emitter {
         std::vector<const Item *> order;
         for (const Item &it : items) order.push_back(&it);
         if (!track) std::stable_sort(order.begin(), order.end(), [&](const Item *x, const Item *y) { return rank(prog.recs, *x) < rank(prog.recs, *y); });
+        // The root's clustered runs that the cell grid covers (program.cpp: grid_runs) are evaluated through the grid; the
+        // hull walk is what lanes outside the grid's box fall back to.
+        std::vector<const Item *> gridded;
+        if (!track && depth == 0 && !prog.grid_runs.empty()) {
+            std::vector<const Item *> others;
+            for (const Item *it : order) {
+                const Rec &r = prog.recs[it->rec];
+                const bool covered = !it->is_list && (r.flags & 15u) == REC_RUN && (r.flags & RUN_CLUSTERED) != 0u &&
+                                     (r.flags & (FOLD_NEG | FOLD_MAX)) == 0u;
+                (covered ? gridded : others).push_back(it);
+            }
+            order = others;
+        }
         for (const Item *it : order) {
             if (!it->is_list) {
                 const unsigned e = evals, f = flops;
@@ -233,6 +246,16 @@ struct Emitter {
             }
         }
         book();
+        if (!gridded.empty()) {
+            s += "    if (sc.grid.cells) {\n    bool outside[NP];\n    bool any_outside = false;\n"
+                 "    grid_fold<NP, COUNT>(sc.grid, sc.pa, sc.pb, p, a0, outside, work);\n"
+                 "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) any_outside = any_outside || outside[n];\n"
+                 "    if (__builtin_amdgcn_ballot_w64(any_outside) != 0) {\n    keep_in_branch();\n    if (any_outside) {\n";
+            for (const Item *it : gridded) leaf(prog.recs[it->rec], depth);
+            s += "    }\n    }\n    } else {\n";
+            for (const Item *it : gridded) leaf(prog.recs[it->rec], depth);
+            s += "    }\n";
+        }
     }
 
     // A nested list.  In the distance-only walk the list is skipped when one of its children

@@ -480,6 +480,48 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
     }
 }
 
+// ---- cell grid: the root's long runs, row lists per cell (device_scene.h: GridView) -------------
+// min(acc, v) over the rows listed for the cell that holds p -- every row that can be the smallest there -- with the
+// plain formulas.  Each lane walks its own cell's list (its own trip count, its own gathers).  outside[n]: p[n] is not in
+// the grid's box (or not a number); its accumulator is left as it is, for the hull walk to finish.
+template <int NP, bool COUNT>
+__device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__restrict__ pa, const Float4 *__restrict__ pb, const V3 (&p)[NP],
+                                          float (&acc)[NP], bool (&outside)[NP], Work (&work)[NP]) {
+    typedef uint32_t Header __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float fx = (p[n].x - g.origin[0]) * g.inv_cell, fy = (p[n].y - g.origin[1]) * g.inv_cell, fz = (p[n].z - g.origin[2]) * g.inv_cell;
+        const bool inside = fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.dims[0] && fy < (float)g.dims[1] && fz < (float)g.dims[2];
+        outside[n] = !inside;
+        if (!inside) continue;
+        const uint32_t cell = ((uint32_t)fz * g.dims[1] + (uint32_t)fy) * g.dims[0] + (uint32_t)fx;
+        const Header head = reinterpret_cast<const Header *>(g.cells)[cell];
+        const uint32_t *e = g.entries + head[0];
+        const uint32_t n_spheres = head[1], n_boxes = head[2], n_crosses = head[3];
+        float a = acc[n];
+        const V3 q = p[n];
+        uint32_t i = 0;
+        for (; i < n_spheres; ++i) {
+            const Float4 ra = pa[e[i]];
+            const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
+            if (!sphere_cannot_change<false, false>(a, d2, ra.w)) a = __builtin_fminf(a, __builtin_sqrtf(d2) - ra.w);
+        }
+        for (; i < n_spheres + n_boxes; ++i) {
+            const uint32_t row = e[i];
+            a = __builtin_fminf(a, prim_distance<K_BOX>(pa[row], pb[row], q));
+        }
+        for (; i < n_spheres + n_boxes + n_crosses; ++i) {
+            const uint32_t row = e[i];
+            a = __builtin_fminf(a, prim_distance<K_CROSS>(pa[row], pb[row], q));
+        }
+        acc[n] = a;
+        if (COUNT) {
+            work[n].evals += n_spheres + n_boxes + n_crosses;
+            work[n].flops += kFlopsSphere * n_spheres + kFlopsBox * n_boxes + kFlopsCross * n_crosses;
+        }
+    }
+}
+
 // interpreter entry: fold known at run time (one of the two a clustered run can have)
 template <uint32_t KIND, int NP, bool COUNT>
 __device__ __forceinline__ void fold_run_clustered_kind(const SceneView &sc, const RecWords &r, const V3 (&p)[NP],

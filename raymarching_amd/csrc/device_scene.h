@@ -119,6 +119,28 @@ constexpr uint32_t flops_of_kind(uint32_t kind) {
     return kind == K_SPHERE ? kFlopsSphere : ((kind == K_BOX || kind == K_BOX_ISO) ? kFlopsBox : kFlopsCross);
 }
 
+// ---- cell grid over the root's long runs ------------------------------------------------------
+// Where the scene's root is a union, the rows of its clustered RUNs (hundreds of loose primitives) are also listed per
+// cell of a uniform grid: cell C lists every row j whose distance can be the smallest of all rows' anywhere in C, i.e.
+// lo_j(C) <= H(C), with lo_j(C) a lower bound of row j's distance over C and H(C) = min_j hi_j(C) the smallest upper
+// bound (interval bounds of the distance formulas over the cell's box, body.cpp:32-57; built on the device when the
+// scene is uploaded, kernels.hip).  At a point of C the runs' fold min(acc, v_j) over all rows equals the fold over C's
+// list: a row not listed is larger than the smallest row value there, so it neither changes the minimum nor ties it.
+// A lane then evaluates about ten rows (its own cell's) where the hull walk visits hundreds for the wave.
+// Points outside the grid's box take the hull walk.
+constexpr uint32_t kGridClassSphere = 0, kGridClassBox = 1, kGridClassCross = 2;
+constexpr uint32_t kGridMaxRuns = 8;
+struct GridRun {
+    uint32_t first, count, cls;   // table rows [first, first + count) (crosses: their first listing), kGridClass*
+};
+struct GridView {
+    const uint32_t *cells;     // null: no grid.  Per cell 4 words: first entry, spheres, boxes, crosses (entries in that order)
+    const uint32_t *entries;   // table rows
+    float origin[3];
+    float inv_cell, cell;
+    uint32_t dims[3];
+};
+
 struct SceneView {
     const Rec *recs;
     const Float4 *pa;
@@ -134,6 +156,7 @@ struct SceneView {
     uint32_t n_lights;
     uint32_t n_prims;
     const float *camera;    // 16 floats of the column-major camera matrix, then the focal length
+    GridView grid;
 };
 
 constexpr uint32_t kTileBits = 27u, kTileMask = (1u << kTileBits) - 1u;

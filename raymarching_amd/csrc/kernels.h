@@ -27,6 +27,23 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sampl
 hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                            uint32_t *prim, float *sd_march, hipStream_t stream);
 
+// The cell grid over the root's long runs (device_scene.h: GridView), built in two passes: count_grid sizes every cell's
+// list (cells[4c + 1..3]), reserves its place (cells[4c], through the counter *total) and keeps the cell's bound H;
+// fill_grid writes the lists.  `total` must be zero before count_grid.
+struct GridBuild {
+    GridRun runs[kGridMaxRuns];   // grouped by class: spheres, boxes, crosses
+    uint32_t n_runs;
+    const Float4 *pa, *pb;
+    float origin[3], cell;
+    uint32_t dims[3];
+    uint32_t *cells;
+    float *bound;                 // H per cell
+    uint32_t *total;
+    uint32_t *entries;            // fill pass
+};
+hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream);
+hipError_t launch_fill_grid(const GridBuild &b, hipStream_t stream);
+
 // Loads this library's ahead-of-time code object on the current device (the runtime would do it at the first launch,
 // inside the first frame).
 hipError_t preload_kernels();

@@ -67,7 +67,102 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
     store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
 }
 
+// ---- cell grid build -------------------------------------------------------------------------
+// Interval bounds of a row's distance (body.cpp:32-57) over a cell's box [lo, hi], widened on the safe side by more than
+// the roundings of these bounds and of the kernels' evaluation of the row at any point of the cell (below 1e-6 of the
+// magnitudes involved): lower bound L, upper bound U.
+__device__ __forceinline__ float med3(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fminf(a, b), __builtin_fminf(__builtin_fmaxf(a, b), c));
+}
+
+__device__ __forceinline__ void row_bounds(uint32_t cls, const Float4 a, const Float4 b, const float (&lo)[3], const float (&hi)[3],
+                                           float &L, float &U) {
+    const float c[3] = { a.x, a.y, a.z };
+    const float h[3] = { a.w, cls == kGridClassSphere ? a.w : b.x, cls == kGridClassSphere ? a.w : b.y };
+    float dmin[3], dmax[3], magnitude = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        dmin[k] = __builtin_fmaxf(__builtin_fmaxf(lo[k] - c[k], c[k] - hi[k]), 0.0f);
+        dmax[k] = __builtin_fmaxf(__builtin_fabsf(lo[k] - c[k]), __builtin_fabsf(hi[k] - c[k]));
+        magnitude += __builtin_fabsf(c[k]) + __builtin_fabsf(h[k]) + __builtin_fabsf(lo[k]) + __builtin_fabsf(hi[k]);
+    }
+    if (cls == kGridClassSphere) {
+        L = __builtin_sqrtf(dmin[0] * dmin[0] + dmin[1] * dmin[1] + dmin[2] * dmin[2]) - a.w;
+        U = __builtin_sqrtf(dmax[0] * dmax[0] + dmax[1] * dmax[1] + dmax[2] * dmax[2]) - a.w;
+    } else if (cls == kGridClassBox) {
+        L = __builtin_fmaxf(__builtin_fmaxf(dmin[0] - h[0], dmin[1] - h[1]), dmin[2] - h[2]);
+        U = __builtin_fmaxf(__builtin_fmaxf(dmax[0] - h[0], dmax[1] - h[1]), dmax[2] - h[2]);
+    } else {   // the cross's distance is the median of its three axis terms, monotone in each of them
+        L = med3(dmin[0] - h[0], dmin[1] - h[1], dmin[2] - h[2]);
+        U = med3(dmax[0] - h[0], dmax[1] - h[1], dmax[2] - h[2]);
+    }
+    const float slack = 4e-6f * magnitude;
+    L = L - slack - 1e-5f * __builtin_fabsf(L);
+    U = U + slack + 1e-5f * __builtin_fabsf(U);
+}
+
+// the cell's box, widened so that a point the kernels' index arithmetic puts into the cell is inside it
+__device__ __forceinline__ void cell_box(const GridBuild &b, uint32_t cell, float (&lo)[3], float (&hi)[3]) {
+    const uint32_t ix = cell % b.dims[0], iy = (cell / b.dims[0]) % b.dims[1], iz = cell / (b.dims[0] * b.dims[1]);
+    const uint32_t i[3] = { ix, iy, iz };
+    for (int k = 0; k < 3; ++k) {
+        const float a = b.origin[k] + (float)i[k] * b.cell, z = b.origin[k] + (float)(i[k] + 1u) * b.cell;
+        const float widen = 1e-3f * b.cell + 1e-5f * (__builtin_fabsf(a) + __builtin_fabsf(z));
+        lo[k] = a - widen;
+        hi[k] = z + widen;
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
+    const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
+    const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+    if (cell >= n_cells) return;
+    float lo[3], hi[3];
+    cell_box(b, cell, lo, hi);
+    float H = __builtin_inff();
+    if (FILL) {
+        H = b.bound[cell];
+    } else {
+        for (uint32_t r = 0; r < b.n_runs; ++r)
+            for (uint32_t i = b.runs[r].first; i < b.runs[r].first + b.runs[r].count; ++i) {
+                float L, U;
+                row_bounds(b.runs[r].cls, b.pa[i], b.pb[i], lo, hi, L, U);
+                H = U < H ? U : H;
+            }
+        b.bound[cell] = H;
+    }
+    uint32_t n[3] = { 0u, 0u, 0u };
+    uint32_t at = FILL ? b.cells[4u * cell] : 0u;
+    for (uint32_t r = 0; r < b.n_runs; ++r)
+        for (uint32_t i = b.runs[r].first; i < b.runs[r].first + b.runs[r].count; ++i) {
+            float L, U;
+            row_bounds(b.runs[r].cls, b.pa[i], b.pb[i], lo, hi, L, U);
+            if (!(L > H)) {   // NaNs are listed
+                if (FILL) b.entries[at++] = i;
+                else n[b.runs[r].cls]++;
+            }
+        }
+    if (!FILL) {
+        b.cells[4u * cell] = atomicAdd(b.total, n[0] + n[1] + n[2]);
+        b.cells[4u * cell + 1u] = n[0];
+        b.cells[4u * cell + 2u] = n[1];
+        b.cells[4u * cell + 3u] = n[2];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream) {
+    const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
+    hipLaunchKernelGGL(grid_kernel<false>, dim3((n_cells + 255u) / 256u), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_grid(const GridBuild &b, hipStream_t stream) {
+    const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
+    hipLaunchKernelGGL(grid_kernel<true>, dim3((n_cells + 255u) / 256u), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
 
 hipError_t preload_kernels() {
     hipFuncAttributes attr;

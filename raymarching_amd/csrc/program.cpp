@@ -422,7 +422,7 @@ struct Compiler {
         return true;
     }
 
-    void emit_run(uint32_t kind, const Bucket &bk, uint32_t fold) {
+    void emit_run(uint32_t kind, const Bucket &bk, uint32_t fold, uint32_t depth) {
         std::vector<Row> rows(bk.node.size());
         for (size_t i = 0; i < rows.size(); i++) {
             halves(nodes[bk.node[i]], rows[i].a, rows[i].b);
@@ -457,6 +457,24 @@ struct Compiler {
                 r.h[0] = supers ? 1u : 0u;
                 r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
                 r.flags |= RUN_CLUSTERED;
+                if (depth == 0 && fold == 0u && out.root_identity > 0 && out.grid_runs.size() < kGridMaxRuns) {
+                    const uint32_t cls = kind == K_SPHERE ? kGridClassSphere : ((kind == K_BOX || kind == K_BOX_ISO) ? kGridClassBox : kGridClassCross);
+                    // the first listing's rows were pushed in sorted order right at r.a[0]
+                    out.grid_runs.push_back(GridRun{ r.a[0], (uint32_t)rows.size(), cls });
+                    const bool first = out.grid_runs.size() == 1;
+                    for (const Row &row : rows) {
+                        double h[3];
+                        extents(kind, row, h);
+                        const double c[3] = { row.a.x, row.a.y, row.a.z };
+                        for (int k = 0; k < 3; k++) {
+                            const double e = cls == kGridClassCross ? std::fmax(h[0], std::fmax(h[1], h[2])) : h[k];
+                            const float lo = (float)(c[k] - e), hi = (float)(c[k] + e);
+                            if (first && &row == &rows[0]) { out.grid_lo[k] = lo; out.grid_hi[k] = hi; }
+                            out.grid_lo[k] = std::fmin(out.grid_lo[k], lo);
+                            out.grid_hi[k] = std::fmax(out.grid_hi[k], hi);
+                        }
+                    }
+                }
             } else {
                 // never expected (the hulls are padded well beyond their rounding); a plain run is always right
                 out.pa.resize(r.a[0]);
@@ -524,7 +542,7 @@ struct Compiler {
         for (uint32_t kind = K_SPHERE; kind <= K_CROSS_ISO; kind++) {
             const Bucket &bk = buckets[kind];
             if (bk.node.size() >= kRunMin) {
-                emit_run(kind, bk, fold_rest);
+                emit_run(kind, bk, fold_rest, depth);
             } else {
                 for (size_t i = 0; i < bk.node.size(); i++) emit_single(nodes[bk.node[i]], bk.prim[i], fold_rest);
             }

@@ -26,6 +26,9 @@ struct HostProgram {
     // algorithmic cost of one scene SDF evaluation: 11 per sphere, 9 per box,
     // 15 per cross (primitive arithmetic + the one compare/select of the fold)
     uint64_t flops_per_sdf = 0;
+    // the root's clustered runs folded with min(acc, v), if the root is a union: what the cell grid covers (device_scene.h)
+    std::vector<GridRun> grid_runs;
+    float grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 };   // box around those runs' primitives (crosses: around their centres)
 };
 
 // Returns false and sets `error` if the node list is not a well-formed tree.
