@@ -160,9 +160,11 @@ def test_closeup6_points_and_tiny_frame(rm, oracle, renderer):
     assert gpu.tobytes() == cpu.tobytes()
 
 
-def test_synthetic1024_frame_bit_identical(rm, oracle, renderer):
-    """configs[4]: 1024 mixed primitives in the root union, 8 lights; small frame against the oracle."""
-    path = scene_path("synthetic1024.txt")
+@pytest.mark.parametrize("name", ["synthetic1024.txt", "synthetic1024_wide.txt"])
+def test_synthetic1024_frame_bit_identical(rm, oracle, renderer, name):
+    """configs[4]: 1024 mixed primitives in the root union, 8 lights; small frame against the oracle.  The second file has
+    every size, the crosses' bar widths included, in [1, 4]: a thicket (long cell lists, most points near many bars)."""
+    path = scene_path(name)
     kw = dict(width=80, height=60, kernel=2)
     renderer.set_params(rm.default_params(**kw))
     renderer.set_scene(rm.Scene(path))

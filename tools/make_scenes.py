@@ -2,7 +2,9 @@
 
   scenes/closeup6.txt       the shipped scene with MengerSponge iterations 6 and a close-up camera
                             (step-count / divergence stress; 3 368 421 crosses)
-  scenes/synthetic1024.txt  1024 primitives cycling Sphere / Box / Cross, 8 lights (seed 12345)
+  scenes/synthetic1024.txt  1024 primitives cycling Sphere / Box / Cross, 8 lights (seed 12345); sphere radii in [0.5, 2],
+                            box sizes in [1, 4], cross bars 0.05-0.3 thick
+  scenes/synthetic1024_wide.txt  the same with every size, the crosses' bars included, uniform in [1, 4]
 
 Deterministic; run from the repo root:  python tools/make_scenes.py
 """
@@ -21,7 +23,7 @@ def closeup6():
     return src
 
 
-def synthetic(n=1024, seed=12345):
+def synthetic(n=1024, seed=12345, wide=False):
     rnd = random.Random(seed)
     u = rnd.uniform
     out = ["Bounds 200.0", "", "Camera Position 50.0 35.0 -2.5", "Camera Direction -1.0 -0.5 -1.0",
@@ -34,16 +36,19 @@ def synthetic(n=1024, seed=12345):
         c = (u(-60, 60), u(1, 30), u(-110, 10))
         kind = i % 3
         if kind == 0:
-            out.append("Sphere %.4f %.4f %.4f %.4f" % (c + (u(0.5, 2),)))
+            out.append("Sphere %.4f %.4f %.4f %.4f" % (c + ((u(1, 4) if wide else u(0.5, 2)),)))
         elif kind == 1:
             out.append("Box %.4f %.4f %.4f %.4f %.4f %.4f" % (c + (u(1, 4), u(1, 4), u(1, 4))))
         else:
-            # a cross is unbounded along its three bars: keep the bars thin
-            out.append("Cross %.4f %.4f %.4f %.4f %.4f %.4f" % (c + (u(0.05, 0.3), u(0.05, 0.3), u(0.05, 0.3))))
+            # a cross is unbounded along its three bars: the first scene keeps the bars thin, the `wide` one does not
+            # (every size uniform in [1, 4]: a thicket of bars that fills much of the room)
+            lo, hi = (1, 4) if wide else (0.05, 0.3)
+            out.append("Cross %.4f %.4f %.4f %.4f %.4f %.4f" % (c + (u(lo, hi), u(lo, hi), u(lo, hi))))
     return "\n".join(out) + "\n"
 
 
 if __name__ == "__main__":
     open(os.path.join(ROOT, "scenes", "closeup6.txt"), "w").write(closeup6())
     open(os.path.join(ROOT, "scenes", "synthetic1024.txt"), "w").write(synthetic())
+    open(os.path.join(ROOT, "scenes", "synthetic1024_wide.txt"), "w").write(synthetic(wide=True))
     print("written")
