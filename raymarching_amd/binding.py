@@ -4,7 +4,8 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch_hip.so")
+# RM_LIB_PATH: another build of the same library (A/B timing of two builds on one GPU box)
+LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraymarch_hip.so")
 
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (

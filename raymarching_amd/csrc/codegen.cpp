@@ -284,17 +284,14 @@ struct Emitter {
             const Rec &b = prog.recs[bound->rec];
             const uint32_t code = b.flags & 15u;
             const bool neg = ((b.flags & FOLD_NEG) != 0) != pop_neg;   // sign of the child's value as the parent sees it
-            s += "    bool need = false;\n";
             if (code == REC_SPHERE) {
-                std::snprintf(buf, sizeof buf,
-                              "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) need = need || !sphere_cannot_change<%s, %s>(%s[n], "
-                              "sphere_d2(p[n], %s, %s, %s), %s);\n",
-                              tf(neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), lit(as_float(b.a[0])).c_str(),
-                              lit(as_float(b.a[1])).c_str(), lit(as_float(b.a[2])).c_str(), lit(as_float(b.h[0])).c_str());
+                std::snprintf(buf, sizeof buf, "    const bool wanted = sphere_bound_wanted<%s, %s, NP>(p, %s, %s, %s, %s, %s);\n", tf(neg).c_str(),
+                              tf(pop_max).c_str(), acc(depth).c_str(), lit(as_float(b.a[0])).c_str(), lit(as_float(b.a[1])).c_str(),
+                              lit(as_float(b.a[2])).c_str(), lit(as_float(b.h[0])).c_str());
             } else {
                 std::snprintf(buf, sizeof buf,
-                              "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) need = need || value_can_change<%s, %s>(%s[n], "
-                              "single_distance<%s>(p[n], %s));\n",
+                              "    bool need = false;\n    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) need = need || value_can_change<%s, %s>(%s[n], "
+                              "single_distance<%s>(p[n], %s));\n    const bool wanted = __builtin_amdgcn_ballot_w64(need) != 0;\n",
                               tf(neg).c_str(), tf(pop_max).c_str(), acc(depth).c_str(), code_name(code), centre_and_half(b).c_str());
             }
             s += buf;
@@ -302,7 +299,7 @@ struct Emitter {
             evals += 1;
             flops += flops_of_code(code);
             book();
-            s += "    if (__builtin_amdgcn_ballot_w64(need) != 0) {\n    keep_in_branch();\n";
+            s += "    if (wanted) {\n    keep_in_branch();\n";
         } else {
             book();
         }

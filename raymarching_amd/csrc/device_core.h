@@ -203,6 +203,24 @@ __device__ __forceinline__ float fold_sphere(float acc, V3 p, float cx, float cy
     return acc;
 }
 
+// Wave-uniform: can folding a list that the sphere (c, r) bounds change some lane's accumulator?  (The list's value is at
+// least, or at most, the sphere's; see codegen.cpp: Emitter::list.)  The largest-coordinate test first, the squared
+// distances only if some lane is not ruled out by it.
+template <bool NEG, bool MAX, int NP>
+__device__ __forceinline__ bool sphere_bound_wanted(const V3 (&p)[NP], const float (&acc)[NP], float cx, float cy, float cz, float r) {
+    if (NEG == MAX) {
+        bool near = false;
+#pragma unroll
+        for (int n = 0; n < NP; ++n) near = near || !sphere_far<NEG>(acc[n], cx - p[n].x, cy - p[n].y, cz - p[n].z, r);
+        if (__builtin_amdgcn_ballot_w64(near) == 0) return false;
+        keep_in_branch();
+    }
+    bool need = false;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) need = need || !sphere_cannot_change<NEG, MAX>(acc[n], sphere_d2(p[n], cx, cy, cz), r);
+    return __builtin_amdgcn_ballot_w64(need) != 0;
+}
+
 // Folds one child value per point into the accumulators (see device_scene.h).
 template <int NP, bool TRACK>
 __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
@@ -763,6 +781,15 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     const uint32_t *ONES = tab + 3 * N;
     if (COUNT) n_evals += 3;
     probe<COUNT>(N == 1 ? kProbeLevel0 : (N == 3 ? kProbeLevel1 : (N == 9 ? kProbeLevel2 : kProbeLevelDeep)), 1u);
+    if (N == 1) {
+        // The one cross of the coarsest level: its centre is the level's origin (a literal here), its digit mask is empty,
+        // and the three rows through it are all this one cross, evaluated with the same operands in the same places.
+        const float dx = __builtin_fabsf(p.x - x0) - h, dy = __builtin_fabsf(p.y - y0) - h, dz = __builtin_fabsf(p.z - z0) - h;
+        const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
+        if ((bx && by) || (bx && bz) || (by && bz)) run = __builtin_fmaxf(run, -cross_value(dx, dy, dz));
+        if (COUNT) n_evals += (bx && by ? 1u : 0u) + (bx && bz ? 1u : 0u) + (by && bz ? 1u : 0u);
+        return kLatticeNext;
+    }
     const int ix = nearest_index(p.x, x0, inv, N - 1), iy = nearest_index(p.y, y0, inv, N - 1), iz = nearest_index(p.z, z0, inv, N - 1);
     const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
     const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];

@@ -25,11 +25,12 @@ namespace rmdev {
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
-                                      const float (&past_light)[kPts], LaneCounts &cnt) {
+                                      const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts]) {
     bool done[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
         done[s] = !live[s];
+        colourless[s] = false;
         if (COUNT && live[s]) cnt.rays++;
     }
     // Upper bound of the next evaluation's result, for the scene walkers that can use one (see `capped` in
@@ -48,8 +49,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         if (all_done) break;
         float sd[kPts];
         Work work[kPts] = {};
-        bool colourless_unused[kPts];
-        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap, colourless_unused);
+        bool colourless_here[kPts];
+        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap, colourless_here);
         probe<COUNT>(kProbeSceneCall, 1u);
         if (COUNT) {
             // the wave sits through this iteration with all of its lanes, whichever of them still march (with one
@@ -60,6 +61,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 #pragma unroll
         for (int s = 0; s < kPts; ++s) {
             if (!done[s]) {
+                colourless[s] = colourless_here[s];   // of the ray's last evaluation, in the end
                 at[s] = p[s];
                 p[s] = p[s] + ray[s] * sd[s];
                 cap[s] = sd[s] + __builtin_fabsf(sd[s]) * 1.00001f +
@@ -203,15 +205,22 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         }
 #pragma unroll
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt);
+        bool colourless[kPts];   // the ray ended on a surface the distance evaluator knows to have colour (0, 0, 0)
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
-            // the Surface scene::surface returned: colour of the last evaluation
-            if (fr.iterations > 0) {
+            // the Surface scene::surface returned: colour of the last evaluation -- from the colour-tracking walk, unless
+            // the distance walk has told already that there is none (the wall behind the scene: most waves of most frames)
+            bool unknown = false;
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) unknown = unknown || (live[s] && !colourless[s]);
+            if (fr.iterations > 0 && __builtin_amdgcn_ballot_w64(unknown) != 0) {
                 float sd_unused[kPts];
                 Scene::template surface<kPts>(sc, lds, at, sd_unused, prim);
             }
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) prim[s] = colourless[s] ? kNoPrim : prim[s];
             // scene::raymarch returns light * colour (scene.cpp:31) with light clamped into [saturation, 1]
             // (scene.cpp:60): where the surface has no colour (the wall behind the scene, 62 % of the shipped
             // frame) the product is zero whatever the normal and the shadow rays turn out to be, so those
