@@ -164,7 +164,7 @@ struct rm_context {
     uint32_t refill_h_log2 = std::getenv("RM_REFILL") ? (uint32_t)(std::atoi(std::getenv("RM_REFILL")) % 10) : 0u;
     int shading = RM_SHADE_COLOURED;
     uint64_t scene_serial = 0;
-    std::string scene_fingerprint;   // bytes that identify the uploaded scene, camera and lights (keys cached tile orders)
+    std::string scene_fingerprint;   // digest of the uploaded scene, camera and lights (keys cached tile orders)
     OrderKey order_key{};
     bool order_ready = false;
     uint32_t measured_tiles_x = 0, measured_tiles_y = 0;
@@ -199,7 +199,7 @@ namespace {
 constexpr int kCompiledPts = 1, kCompiledWaves = 4;
 constexpr size_t kSixteenthTiles = 16, kQuarterTiles = 32;   // how many of the longest tiles are launched in 16 and in 4 parts
 
-// What a measured tile order depends on, as bytes: the scene as uploaded (records, tables, camera, lights), the
+// What a measured tile order depends on, as bytes: a digest of the scene as uploaded (records, tables, camera, lights), the
 // parameters, the row bands and the launch shape.  Keys the tile orders kept in the kernel cache directory, so that
 // the first frame of a configuration some earlier process has rendered starts in cost order without being timed.
 std::string order_cache_key(const rm_context *ctx, const rm_context::OrderKey &key, const std::vector<uint32_t> &band_list) {
@@ -227,6 +227,63 @@ rmdev::FrameView frame_view(const rm_params &p, const rm_rows &rows) {
     return f;
 }
 
+// Launch shape of a render.  Record walker: one wave of 8 x 8 samples per workgroup, or 2 x 2 waves with two samples per lane.
+// Kernels generated for the scene: n x n waves per workgroup, n = 1 for the finest scheduling (a workgroup lasts as
+// long as its slowest wave), 2 where large lattice tables are staged into LDS by every workgroup; they write the
+// pixels themselves when a tile of 8n x 8n samples holds whole pixels, otherwise the trace kernel writes samples and
+// the resolve kernel adds them up.  n = 3 would hold whole pixels for SSAA kernels 3, 6, 12 and 24 too, but nine-wave
+// workgroups fill a CU's wave slots so unevenly that the shipped frame takes 0.82-0.99 ms instead of 0.58 with the
+// resolve kernel (measured): that shape is used only where the sample image has nowhere to go (static scratch too small).
+struct LaunchShape {
+    bool compiled, fused, refill;
+    uint32_t n_side, pts;
+    size_t n_tiles;
+};
+
+LaunchShape launch_shape(const rm_context *ctx, rmdev::FrameView &fr, bool has_output, bool static_samples) {
+    LaunchShape s{};
+    s.compiled = ctx->module.loaded();
+    const bool wide_runs = ctx->program.run_prims >= 64;
+    const bool large_tables = ctx->program.lattice.size() > 1024;
+    s.n_side = s.compiled ? (large_tables ? 2u : 1u) : (wide_runs ? 1u : 2u);
+    if (s.compiled && has_output) {
+        const uint32_t k = fr.kernel;
+        if ((8u * s.n_side) % k == 0u) {
+            s.fused = true;
+        } else if (static_samples && 24u % k == 0u && rmdev::sample_texels(fr) * sizeof(rmdev::Sample) > kStaticScratchBytes) {
+            s.n_side = 3u;
+            s.fused = true;
+        }
+    }
+    s.refill = s.compiled && ctx->refill_w_log2 >= 3u && ctx->refill_h_log2 >= 3u && ctx->module.trace_refill != nullptr &&
+               fr.iterations > 0 && !static_samples;
+    if (s.refill) {
+        s.fused = false;
+        s.n_side = 1u;
+        fr.refill_w_log2 = ctx->refill_w_log2;
+        fr.refill_h_log2 = ctx->refill_h_log2;
+    }
+    s.pts = s.compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
+    const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel, side = 8u * s.n_side;
+    s.n_tiles = (size_t)((sw + side * s.pts - 1u) / (side * s.pts)) * ((sh + side - 1u) / side);
+    if (s.refill) s.n_tiles = (size_t)((sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2) * ((sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2);
+    return s;
+}
+
+// what the tile order of such a launch depends on
+rm_context::OrderKey order_key_of(const rm_context *ctx, const rm_rows &rows, const LaunchShape &shape, const rmdev::FrameView &fr) {
+    rm_context::OrderKey key{};
+    key.params = ctx->params;
+    key.rows = rows;
+    key.scene_serial = ctx->scene_serial;
+    key.band_list_serial = ctx->band_list_size ? ctx->band_list_serial : 0;
+    key.points_per_lane = shape.pts;
+    key.shading = (uint32_t)ctx->shading;
+    key.fused = shape.fused ? 1u : 0u;
+    key.waves_per_side = shape.refill ? 100u + 16u * fr.refill_w_log2 + fr.refill_h_log2 : shape.n_side;
+    return key;
+}
+
 // Trace + resolve of the given bands into device buffers; synchronises the stream.
 // Puts trace + resolve of the given bands on the context's stream.  may_measure: this frame may run in
 // natural tile order with every tile timed (its caller will call finish_bands before the next frame).
@@ -236,15 +293,38 @@ bool load_tile_order(rm_context *ctx, const rm_context::OrderKey &key, size_t n_
     if (!rmdev::load_cached_blob("tile-order:", order_cache_key(ctx, key, ctx->band_list_host), entries)) return false;
     if (entries.size() < n_tiles || entries.size() > n_tiles * 16u) return false;
     // every tile must be covered exactly: whole, or as its 4 quarters, or as its 16 sixteenths (a damaged file must
-    // not leave pixels unrendered)
-    std::vector<uint32_t> covered(n_tiles, 0u);
+    // not leave pixels unrendered).  Whole tiles are ticked off in a bitmap that stays in cache (the entries come in
+    // cost order, i.e. at random), the few split tiles are counted apart.
+    std::vector<uint64_t> whole((n_tiles + 63u) / 64u, 0ull);
+    std::vector<std::pair<uint32_t, uint32_t>> parts;   // (tile, part: 1-4 its quarters, 5-20 its sixteenths)
+    size_t n_whole = 0;
     for (uint32_t e : entries) {
         const uint32_t tile = e & rmdev::kTileMask, part = e >> rmdev::kTileBits;
         if (tile >= n_tiles || part > 20u) return false;
-        covered[tile] += part == 0u ? 16u : (part < 5u ? 4u : 1u);
+        if (part == 0u) {
+            const uint64_t bit = 1ull << (tile & 63u);
+            if (whole[tile >> 6] & bit) return false;
+            whole[tile >> 6] |= bit;
+            n_whole++;
+        } else {
+            if (parts.size() >= 4096u) return false;   // far more than any order splits
+            parts.emplace_back(tile, part);
+        }
     }
-    for (uint32_t c : covered)
-        if (c != 16u) return false;
+    std::sort(parts.begin(), parts.end());
+    size_t n_split = 0;
+    for (size_t i = 0; i < parts.size();) {
+        // sorted: a split tile's entries must read 1, 2, 3, 4 or 5, 6, ..., 20
+        const uint32_t tile = parts[i].first, first = parts[i].second, count = first == 1u ? 4u : 16u;
+        if ((first != 1u && first != 5u) || i + count > parts.size()) return false;
+        size_t j = i;
+        for (; j < i + count; j++)
+            if (parts[j].first != tile || parts[j].second != first + (uint32_t)(j - i)) return false;
+        if ((j < parts.size() && parts[j].first == tile) || (whole[tile >> 6] >> (tile & 63u) & 1ull)) return false;
+        n_split++;
+        i = j;
+    }
+    if (n_whole + n_split != n_tiles) return false;
     if (ctx->d_tile_order.reserve(entries.size()) != hipSuccess || ctx->h_tiles.reserve(entries.size()) != hipSuccess) return false;
     std::memcpy(ctx->h_tiles.ptr, entries.data(), entries.size() * sizeof(uint32_t));
     // ordered before the launch that follows on the same stream; the staging words stay untouched until that frame is waited for
@@ -269,35 +349,10 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         fr.band_list = ctx->d_band_list.ptr;
     }
     fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
-    const bool compiled = ctx->module.loaded();
+    const LaunchShape shape = launch_shape(ctx, fr, d_f32 || d_rgba8, static_samples != nullptr);
+    const bool compiled = shape.compiled, fused = shape.fused, refill = shape.refill;
     const bool wide_runs = ctx->program.run_prims >= 64;
-    // Launch shape.  Record walker: one wave of 8 x 8 samples per workgroup, or 2 x 2 waves with two samples per lane.
-    // Kernels generated for the scene: n x n waves per workgroup, n = 1 for the finest scheduling (a workgroup lasts as
-    // long as its slowest wave), 2 where large lattice tables are staged into LDS by every workgroup; they write the
-    // pixels themselves when a tile of 8n x 8n samples holds whole pixels, otherwise the trace kernel writes samples and
-    // the resolve kernel adds them up.  n = 3 would hold whole pixels for SSAA kernels 3, 6, 12 and 24 too, but nine-wave
-    // workgroups fill a CU's wave slots so unevenly that the shipped frame takes 0.82-0.99 ms instead of 0.58 with the
-    // resolve kernel (measured): that shape is used only where the sample image has nowhere to go (static scratch too small).
-    const bool large_tables = ctx->program.lattice.size() > 1024;
-    uint32_t n_side = compiled ? (large_tables ? 2u : 1u) : (wide_runs ? 1u : 2u);
-    bool fused = false;
-    if (compiled && (d_f32 || d_rgba8)) {
-        const uint32_t k = fr.kernel;
-        if ((8u * n_side) % k == 0u) {
-            fused = true;
-        } else if (static_samples && 24u % k == 0u && rmdev::sample_texels(fr) * sizeof(rmdev::Sample) > kStaticScratchBytes) {
-            n_side = 3u;
-            fused = true;
-        }
-    }
-    const bool refill = compiled && ctx->refill_w_log2 >= 3u && ctx->refill_h_log2 >= 3u && ctx->module.trace_refill != nullptr &&
-                        fr.iterations > 0 && !static_samples;
-    if (refill) {
-        fused = false;
-        n_side = 1u;
-        fr.refill_w_log2 = ctx->refill_w_log2;
-        fr.refill_h_log2 = ctx->refill_h_log2;
-    }
+    const uint32_t n_side = shape.n_side;
     if (fused) {
         fr.pixels_f32 = d_f32;
         fr.pixels_rgba8 = d_rgba8;
@@ -316,21 +371,12 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     pend.compiled = compiled;
 
     // ---- tile schedule of this launch
-    const uint32_t pts = compiled ? (uint32_t)kCompiledPts : (wide_runs ? 1u : 2u);
+    const uint32_t pts = shape.pts;
     const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
     const uint32_t side = 8u * n_side;
-    pend.n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
-    if (refill) pend.n_tiles = (size_t)((sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2) * ((sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2);
+    pend.n_tiles = shape.n_tiles;
     if (ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && pend.n_tiles > 1) {
-        rm_context::OrderKey key{};
-        key.params = ctx->params;
-        key.rows = rows;
-        key.scene_serial = ctx->scene_serial;
-        key.band_list_serial = ctx->band_list_size ? ctx->band_list_serial : 0;
-        key.points_per_lane = pts;
-        key.shading = (uint32_t)ctx->shading;
-        key.fused = fused ? 1u : 0u;
-        key.waves_per_side = refill ? 100u + 16u * fr.refill_w_log2 + fr.refill_h_log2 : n_side;
+        const rm_context::OrderKey key = order_key_of(ctx, rows, shape, fr);
         if (ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) {
             fr.tile_order = ctx->d_tile_order.ptr;
             fr.extra_slots = ctx->order_extra;
@@ -634,6 +680,18 @@ int rm_reserve(rm_context *ctx) {
     RM_HIP(hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, tiles * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
+    // the whole frame's tile order, if an earlier process left one for this configuration: read and checked here
+    // (milliseconds for a 4K frame's half a million tiles), so that the first frame starts in cost order at once
+    if (ctx->have_scene && ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && !ctx->band_list_size) {
+        const rm_rows whole = { p.height, 0, 1, 1 };
+        rmdev::FrameView fr = frame_view(p, whole);
+        const LaunchShape shape = launch_shape(ctx, fr, true, false);
+        if (shape.n_tiles > 1) {
+            const rm_context::OrderKey key = order_key_of(ctx, whole, shape, fr);
+            if (!(ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) && load_tile_order(ctx, key, shape.n_tiles))
+                RM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
     return RM_OK;
 }
 
@@ -683,9 +741,23 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     if (int rc = build_grid(ctx)) return rc;
     ctx->scene_serial++;
     {
-        std::string &fp = ctx->scene_fingerprint;
-        fp.clear();
-        auto add = [&fp](const void *data, size_t bytes) { fp.append(static_cast<const char *>(data), bytes); };
+        // Two 64-bit multiply-xor digests over the uploaded bytes, eight at a time (a Menger-6 scene has 54 MB of colours:
+        // the bytes themselves would make every cache key that long).  A collision would load another scene's tile
+        // order, which load_tile_order accepts only if it covers every tile exactly once: a slower frame, never a wrong one.
+        uint64_t d0 = 0x9e3779b97f4a7c15ull, d1 = 0xc2b2ae3d27d4eb4full, total = 0;
+        auto add = [&](const void *data, size_t bytes) {
+            const unsigned char *b = static_cast<const unsigned char *>(data);
+            total += bytes;
+            for (size_t i = 0; i < bytes; i += 8) {
+                uint64_t w = 0;
+                std::memcpy(&w, b + i, bytes - i < 8 ? bytes - i : 8);
+                d0 = (d0 ^ w) * 0x100000001b3ull;
+                d0 ^= d0 >> 29;
+                d1 = (d1 + w) * 0xff51afd7ed558ccdull;
+                d1 ^= d1 >> 32;
+            }
+            d0 = (d0 ^ bytes) * 0x100000001b3ull;   // the parts' lengths count too
+        };
         const rmdev::HostProgram &hp = ctx->program;
         add(hp.recs.data(), hp.recs.size() * sizeof(rmdev::Rec));
         add(hp.pa.data(), hp.pa.size() * sizeof(rmdev::Float4));
@@ -696,6 +768,8 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         add(lights.data(), lights.size() * sizeof(rmdev::Float4));
         const int modes[2] = { ctx->kernel_mode, ctx->evaluator };
         add(modes, sizeof modes);
+        const uint64_t digest[3] = { d0, d1, total };
+        ctx->scene_fingerprint.assign(reinterpret_cast<const char *>(digest), sizeof digest);
     }
     ctx->module.unload();
     ctx->counting_module.unload();
