@@ -128,8 +128,9 @@ int rm_set_params(rm_context *ctx, const rm_params *params);
 
 /* Replaces render::setup::buffers (render.cpp:439-445): sizes the device buffers whole-frame renders of the current
  * parameters need (frame, SSAA samples, tile tables), so that the first frame does not pay for them, and -- with a scene
- * set -- reads the whole frame's tile order if an earlier process left one in the cache directory.  Optional: every
- * render sizes and loads what it lacks.  Not while a frame is queued (rm_enqueue_*): the buffers are cleared. */
+ * set -- reads the whole frame's tile order if an earlier process left one in the cache directory (rm_set_scene does
+ * the same once the parameters are known, so either order of the two calls serves).  Optional: every render sizes and
+ * loads what it lacks.  Not while a frame is queued (rm_enqueue_*): the buffers are cleared. */
 int rm_reserve(rm_context *ctx);
 
 /* Replaces render::push's scene part: genscene + genlights + 3x pushssbo and the

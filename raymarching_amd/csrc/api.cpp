@@ -197,7 +197,22 @@ namespace {
 // sample would double the divergent lattice walks.  128 registers per lane (4 waves per SIMD)
 // avoid all spills.
 constexpr int kCompiledPts = 1, kCompiledWaves = 4;
-constexpr size_t kSixteenthTiles = 16, kQuarterTiles = 32;   // how many of the longest tiles are launched in 16 and in 4 parts
+// how many of the longest tiles are launched in 16 and in 4 parts; $RM_SPLIT_TILES=S,Q overrides the counts for sweeps
+// (orders in the cache directory are not keyed by them: sweep with the cache off)
+struct SplitCounts { size_t sixteenths = 16, quarters = 32; };
+const SplitCounts &split_counts() {
+    static const SplitCounts counts = [] {
+        SplitCounts c;
+        if (const char *env = std::getenv("RM_SPLIT_TILES")) {
+            unsigned long s16 = 0, q = 0;
+            if (std::sscanf(env, "%lu,%lu", &s16, &q) == 2 && s16 <= 4096 && q <= 4096) { c.sixteenths = s16; c.quarters = q; }
+        }
+        return c;
+    }();
+    return counts;
+}
+#define kSixteenthTiles (split_counts().sixteenths)
+#define kQuarterTiles (split_counts().quarters)
 
 // What a measured tile order depends on, as bytes: a digest of the scene as uploaded (records, tables, camera, lights), the
 // parameters, the row bands and the launch shape.  Keys the tile orders kept in the kernel cache directory, so that
@@ -333,6 +348,22 @@ bool load_tile_order(rm_context *ctx, const rm_context::OrderKey &key, size_t n_
     ctx->order_key = key;
     ctx->order_ready = true;
     return true;
+}
+
+// The whole frame's tile order, if an earlier process left one for this configuration: read and checked when the
+// buffers are reserved or the scene is uploaded, whichever comes last (milliseconds for a 4K frame's half a million
+// tiles), so that the first frame starts in cost order at once.
+int preload_tile_order(rm_context *ctx) {
+    if (!ctx->have_scene || !ctx->have_params || ctx->tile_scheduling != RM_TILES_BY_COST || ctx->counting || ctx->band_list_size) return RM_OK;
+    const rm_params &p = ctx->params;
+    const rm_rows whole = { p.height, 0, 1, 1 };
+    rmdev::FrameView fr = frame_view(p, whole);
+    const LaunchShape shape = launch_shape(ctx, fr, true, false);
+    if (shape.n_tiles <= 1) return RM_OK;
+    const rm_context::OrderKey key = order_key_of(ctx, whole, shape, fr);
+    if (!(ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) && load_tile_order(ctx, key, shape.n_tiles))
+        RM_HIP(hipStreamSynchronize(ctx->stream));
+    return RM_OK;
 }
 
 // static_samples: the device's static scratch (rm_enqueue_device_static) -- the call then allocates nothing: the sample
@@ -684,19 +715,7 @@ int rm_reserve(rm_context *ctx) {
     RM_HIP(hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, tiles * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
-    // the whole frame's tile order, if an earlier process left one for this configuration: read and checked here
-    // (milliseconds for a 4K frame's half a million tiles), so that the first frame starts in cost order at once
-    if (ctx->have_scene && ctx->tile_scheduling == RM_TILES_BY_COST && !ctx->counting && !ctx->band_list_size) {
-        const rm_rows whole = { p.height, 0, 1, 1 };
-        rmdev::FrameView fr = frame_view(p, whole);
-        const LaunchShape shape = launch_shape(ctx, fr, true, false);
-        if (shape.n_tiles > 1) {
-            const rm_context::OrderKey key = order_key_of(ctx, whole, shape, fr);
-            if (!(ctx->order_ready && std::memcmp(&key, &ctx->order_key, sizeof key) == 0) && load_tile_order(ctx, key, shape.n_tiles))
-                RM_HIP(hipStreamSynchronize(ctx->stream));
-        }
-    }
-    return RM_OK;
+    return preload_tile_order(ctx);
 }
 
 int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const float *lights_xyz, uint32_t n_lights,
@@ -800,7 +819,7 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
             RM_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
-    return RM_OK;
+    return preload_tile_order(ctx);
 }
 
 int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {

@@ -10,7 +10,8 @@ timeout -k 10 300 python3 -u bench.py > "$OUT/bench_default.json" 2> "$OUT/bench
 bash tools/emulate_scaling.sh > "$OUT/emulate_scaling.txt" 2>&1
 timeout -k 10 300 python3 tools/march_util.py default uhd menger2 closeup6 synthetic synthetic_wide > "$OUT/march_util.txt" 2>/dev/null
 for w in menger2 uhd closeup6 synthetic synthetic_wide; do
-    timeout -k 10 300 python3 -u bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
+    steps=10; [ $w = menger2 ] && steps=200   # a menger2 frame is 0.1 ms: few frames time the launch, not the frame
+    timeout -k 10 300 python3 -u bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
 done
 cd /tmp
 export TMPDIR=/tmp
@@ -26,7 +27,7 @@ timeout -s KILL 90 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ
 timeout -s KILL 90 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_WAVES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA -d "$OUT/pmc_sq2" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" default 3 > "$OUT/pmc_sq2.log" 2>&1
 python3 "$REPO/tools/pmc_summary.py" "$OUT" > "$OUT/pmc_default_compiled.txt"
 python3 "$REPO/tools/collect_traffic.py" --fetch "$OUT/pmc_fetch" --write "$OUT/pmc_write" --sq "$OUT/pmc_sq1" --workload default --evaluator lattice --kernel-mode compiled --out "$OUT/traffic.json"
-for w in menger2 uhd; do
+for w in menger2 uhd closeup6 synthetic; do
     timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_fetch_$w.log" 2>&1
     timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_write_$w.log" 2>&1
     timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_sq1_$w" -o p --output-format csv -- python3 "$REPO/tools/one_frame.py" $w 3 > "$OUT/pmc_sq1_$w.log" 2>&1
