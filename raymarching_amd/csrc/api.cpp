@@ -693,6 +693,7 @@ int rm_reserve(rm_context *ctx) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (!ctx->have_params) return fail(RM_ERR_STATE, "rm_set_params has not been called");
     RM_HIP(hipSetDevice(ctx->device));
+    ctx->order_ready = false;   // the tile tables are cleared below: an order they held is read again, or measured again
     const rm_params &p = ctx->params;
     const size_t pixels = (size_t)p.width * p.height;
     RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));

@@ -33,6 +33,22 @@ def test_tile_order_and_kernels_come_back_from_the_cache_directory(rm, tmp_path)
         cb = b.counters()
         assert cb["tiles_by_cost"] == 1 and cb["tile_parts"] == ca["tile_parts"]   # first frame already in the measured order
         assert again.tobytes() == first.tobytes() == second.tobytes()
+        # rm_reserve clears the tile tables: the order is read again, whichever of the two calls comes last,
+        # and a reserve between two frames costs a frame in natural order at most, never a wrong one
+        for reserve_first in (True, False):
+            d = rm.Renderer(0)
+            d.set_params(p)
+            if reserve_first:
+                d.reserve()
+            d.set_scene(scene)
+            if not reserve_first:
+                d.reserve()
+            assert d.render_f32().tobytes() == first.tobytes()
+            assert d.counters()["tiles_by_cost"] == 1
+            d.reserve()
+            assert d.render_f32().tobytes() == first.tobytes()
+            assert d.render_rgba8().tobytes() == b.render_rgba8().tobytes()
+            d.close()
         # another camera is another configuration
         moved = rm.Scene(text=open(scene_path("default.txt")).read().replace("Camera Position 50.0", "Camera Position 49.0"))
         b.set_scene(moved)
