@@ -148,8 +148,8 @@ struct Emitter {
             flops += flops_of_code(code);
         } else if (code == REC_RUN && (r.flags & RUN_CLUSTERED) && !track) {
             std::snprintf(buf, sizeof buf,
-                          "    fold_run_clustered<%s, %s, %s, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, %uu, %uu, %s, %s, p, %s, %s, work);\n",
-                          kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), r.a[0], r.a[1], tf(r.h[0] != 0u).c_str(), lit(as_float(r.h[2])).c_str(),
+                          "    fold_run_clustered<%s, %s, %s, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, %uu, %uu, %s, p, %s, %s, work);\n",
+                          kind_name(r.a[2]), tf(neg).c_str(), tf(mx).c_str(), r.a[0], r.a[1], lit(as_float(r.h[2])).c_str(),
                           acc(depth).c_str(), (depth == 0 && !neg && !mx && prog.root_identity > 0) ? "cap" : "no_cap");
         } else if (code == REC_RUN) {
             std::snprintf(buf, sizeof buf,

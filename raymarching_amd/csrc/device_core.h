@@ -464,7 +464,7 @@ __device__ __forceinline__ void fold_listing(ConstRows pa, ConstRows pb, uint32_
 }
 
 template <uint32_t KIND, bool NEG, bool MAX, int NP, bool COUNT>
-__device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count, bool has_supers,
+__device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, uint32_t first, uint32_t count,
                                                    float magnitude, const V3 (&p)[NP], float (&acc)[NP], const float (&cap)[NP],
                                                    Work (&work)[NP]) {
     static_assert(NEG == MAX, "hulls give lower bounds: only folds that keep small distances can use them");
@@ -477,7 +477,7 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
     const float centre_eps = 2e-6f * (__builtin_fabsf(ball.centre.x) + __builtin_fabsf(ball.centre.y) + __builtin_fabsf(ball.centre.z) + magnitude);
     if (KIND == K_CROSS || KIND == K_CROSS_ISO) {
         const uint32_t n_clusters = (count + kClusterSize - 1u) / kClusterSize;
-        const uint32_t stride = count + n_clusters + (has_supers ? (n_clusters + kClusterSize - 1u) / kClusterSize : 0u);
+        const uint32_t stride = count + n_clusters;
         fold_listing<KIND, 0, NEG, MAX, NP>(pa, pb, first, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
         fold_listing<KIND, 1, NEG, MAX, NP>(pa, pb, first + stride, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
         fold_listing<KIND, 2, NEG, MAX, NP>(pa, pb, first + 2u * stride, count, ball, centre_eps, p, acc, cap, eps, tested, evaluated);
@@ -548,9 +548,9 @@ __device__ __forceinline__ void fold_run_clustered_kind(const SceneView &sc, con
 #pragma unroll
     for (int n = 0; n < NP; ++n) no_cap[n] = __builtin_inff();
     if (r[6] & FOLD_MAX)
-        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, no_cap, work);
+        fold_run_clustered<KIND, true, true, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], __uint_as_float(r[5]), p, acc, no_cap, work);
     else
-        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], r[3] != 0u, __uint_as_float(r[5]), p, acc, no_cap, work);
+        fold_run_clustered<KIND, false, false, NP, COUNT>((ConstRows)sc.pa, (ConstRows)sc.pb, r[0], r[1], __uint_as_float(r[5]), p, acc, no_cap, work);
 }
 
 // ---- LATTICE: a complete Menger lattice of cubic crosses, folded with max(s, -cross) ----------

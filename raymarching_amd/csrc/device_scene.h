@@ -43,7 +43,7 @@ enum Kind : uint32_t { K_SPHERE = 1, K_BOX = 2, K_CROSS = 3, K_BOX_ISO = 4, K_CR
 enum FoldBits : uint32_t { FOLD_NEG = 16u, FOLD_MAX = 32u };
 // RUN only: the run's rows are sorted in space and come with bounding hulls (see below)
 constexpr uint32_t RUN_CLUSTERED = 64u;
-constexpr uint32_t kClusterSize = 8;        // rows per cluster, clusters per super-cluster
+constexpr uint32_t kClusterSize = 8;        // rows per hull of a clustered run
 constexpr uint32_t kNoRow = 0xffffffffu;
 
 // 32 bytes, wave-uniform, fetched with one scalar load (s_load_dwordx8).
@@ -53,12 +53,11 @@ constexpr uint32_t kNoRow = 0xffffffffu;
 //              gathered in depth-first order (a fold may run in any order: ties between equal
 //              distances are broken by depth-first index, which keeps the earlier child)
 //              With RUN_CLUSTERED (folds that keep small values of v: min(s, c) and max(s, -c)):
-//              h = (1 if there are hulls of hulls, unused, magnitude bound as float bits).  The
+//              h = (unused, unused, magnitude bound as float bits).  The
 //              run's rows are sorted along a space-filling curve and followed, in the tables, by
 //              a hull row per 8 consecutive rows -- a primitive of the same kind (sphere, box)
-//              that contains them, so that its distance is a lower bound of theirs -- and, for
-//              runs of 128 rows or more, a hull per 8 hulls.  A hull whose distance cannot beat
-//              the accumulator rules out all rows below it.  Runs of crosses hold three such
+//              that contains them, so that its distance is a lower bound of theirs.  A hull whose
+//              distance cannot beat the accumulator rules out its rows.  Runs of crosses hold three such
 //              listings back to back, one per bar direction (device_core.h: bar_hull_needs_rows).
 //   LATTICE:   a = (levels, table offset in words, count) as integers, prim = first row
 //   PUSH:      a[0] = slot, a[1] = identity of the list that starts (float bits)

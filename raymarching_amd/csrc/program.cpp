@@ -356,9 +356,8 @@ struct Compiler {
     }
 
     // One listing of a clustered run: the rows sorted along a Morton curve (over all three centre
-    // coordinates, or over the two that place the bars of direction `dir`), a hull per 8 rows, and
-    // for long runs a hull per 64.
-    bool emit_listing(uint32_t kind, int dir, std::vector<Row> rows, bool supers) {
+    // coordinates, or over the two that place the bars of direction `dir`), then a hull per 8 rows.
+    bool emit_listing(uint32_t kind, int dir, std::vector<Row> rows) {
         double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (const Row &row : rows) {
             const double c[3] = { row.a.x, row.a.y, row.a.z };
@@ -386,15 +385,6 @@ struct Compiler {
             const Row hull = hull_of(kind, dir, rows, i0, i1);
             sound = sound && contains(kind, dir, hull, rows, i0, i1);
             push_row(hull);
-        }
-        if (supers) {
-            const size_t per = (size_t)kClusterSize * kClusterSize, n_supers = (n_clusters + kClusterSize - 1) / kClusterSize;
-            for (size_t s = 0; s < n_supers; s++) {
-                const size_t i0 = s * per, i1 = std::min(rows.size(), (s + 1) * per);
-                const Row hull = hull_of(kind, dir, rows, i0, i1);
-                sound = sound && contains(kind, dir, hull, rows, i0, i1);
-                push_row(hull);
-            }
         }
         return sound;
     }
@@ -446,15 +436,13 @@ struct Compiler {
             }
         }
         if (use_lattice && keeps_small && finite && rows.size() >= 2 * kClusterSize) {
-            const bool supers = rows.size() >= 2 * kClusterSize * kClusterSize;
             bool sound = true;
             if (kind == K_CROSS || kind == K_CROSS_ISO) {
-                for (int dir = 0; dir < 3; dir++) sound = emit_listing(kind, dir, rows, supers) && sound;
+                for (int dir = 0; dir < 3; dir++) sound = emit_listing(kind, dir, rows) && sound;
             } else {
-                sound = emit_listing(kind, -1, rows, supers);
+                sound = emit_listing(kind, -1, rows);
             }
             if (sound) {
-                r.h[0] = supers ? 1u : 0u;
                 r.h[2] = bits_of((float)(3.0 * magnitude * (1.0 + 1e-5)));
                 r.flags |= RUN_CLUSTERED;
                 if (depth == 0 && fold == 0u && out.root_identity > 0 && out.grid_runs.size() < kGridMaxRuns) {
