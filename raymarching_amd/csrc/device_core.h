@@ -597,28 +597,38 @@ __device__ __forceinline__ void axis_range(const uint32_t *tab, int n, float p, 
 // n centres of the level.  AXIS = the running axis; the operands keep their x, y, z places in the
 // reference's sum.  `fixed_ones` = digit masks of the two fixed indices, or-ed.  (Reading the row's
 // tables through the scalar unit instead of LDS was measured slower: 1.15 vs 1.05 ms per default frame.)
+// What the cell contributes to the row's maximum: -cross(p), or minus infinity for a cell that names no sub-cube.
+template <int AXIS>
+__device__ __forceinline__ float lattice_cell_value(float coord, uint32_t ones, float pt, float h, float d1, float d2, uint32_t fixed_ones) {
+    const float t = __builtin_fabsf(pt - coord) - h;
+    const float v = -(AXIS == 0 ? cross_value(t, d1, d2) : (AXIS == 1 ? cross_value(d1, t, d2) : cross_value(d1, d2, t)));
+    return (ones & fixed_ones) ? -__builtin_inff() : v;
+}
+
 template <int AXIS>
 __device__ __forceinline__ float lattice_cell(float coord, uint32_t ones, float pt, float h, float d1, float d2,
                                               uint32_t fixed_ones, float run) {
-    const float t = __builtin_fabsf(pt - coord) - h;
-    const float v = -(AXIS == 0 ? cross_value(t, d1, d2) : (AXIS == 1 ? cross_value(d1, t, d2) : cross_value(d1, d2, t)));
-    return (ones & fixed_ones) ? run : __builtin_fmaxf(run, v);
+    return __builtin_fmaxf(run, lattice_cell_value<AXIS>(coord, ones, pt, h, d1, d2, fixed_ones));
 }
 
+// The row's cells are folded among themselves first (from minus infinity: every operand of those maxima is a fresh
+// arithmetic result or a constant, which spares the compiler a canonicalising copy of the running value per cell),
+// then into the running value; a maximum does not depend on the order.
 template <int AXIS>
 __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONES, int n, float pt, float h, float d1, float d2,
                                              uint32_t fixed_ones, float run) {
     if (n == 1) return lattice_cell<AXIS>(T[0], ONES[0], pt, h, d1, d2, fixed_ones, run);
     // n is a power of 3: three table entries are read together, then evaluated, so the loop waits for
     // LDS once per three crosses (batches of nine measured slower: 1.19 vs 1.07 ms per default frame)
+    float best = -__builtin_inff();
     for (int k = 0; k < n; k += 3) {
         const float c0 = T[k], c1 = T[k + 1], c2 = T[k + 2];
         const uint32_t o0 = ONES[k], o1 = ONES[k + 1], o2 = ONES[k + 2];
-        run = lattice_cell<AXIS>(c0, o0, pt, h, d1, d2, fixed_ones, run);
-        run = lattice_cell<AXIS>(c1, o1, pt, h, d1, d2, fixed_ones, run);
-        run = lattice_cell<AXIS>(c2, o2, pt, h, d1, d2, fixed_ones, run);
+        best = __builtin_fmaxf(best, lattice_cell_value<AXIS>(c0, o0, pt, h, d1, d2, fixed_ones));
+        best = __builtin_fmaxf(best, lattice_cell_value<AXIS>(c1, o1, pt, h, d1, d2, fixed_ones));
+        best = __builtin_fmaxf(best, lattice_cell_value<AXIS>(c2, o2, pt, h, d1, d2, fixed_ones));
     }
-    return run;
+    return __builtin_fmaxf(run, best);
 }
 
 // Rows of the lanes that have one (`active`), evaluated either by every such lane for itself
@@ -632,6 +642,8 @@ __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONE
 template <int AXIS, bool COUNT = false>
 __device__ __forceinline__ float lattice_rows(bool active, const float *T, const uint32_t *ONES, int n, float pt, float h, float d1,
                                               float d2, uint32_t fixed_ones, float run) {
+    // short rows: every owner walks its own, and a plain branch skips the walk when no lane has one
+    if (!COUNT && n < 27) return active ? lattice_row<AXIS>(T, ONES, n, pt, h, d1, d2, fixed_ones, run) : run;
     const unsigned long long rows = __builtin_amdgcn_ballot_w64(active);
     if (rows == 0) return run;
     if (COUNT) {
