@@ -519,16 +519,17 @@ __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__res
         float a = acc[n];
         const V3 q = p[n];
         uint32_t i = 0;
-        for (; i < n_spheres; ++i) {
+        // (lists are a few rows long: unrolled loops only cost registers here)
+        _Pragma("nounroll") for (; i < n_spheres; ++i) {
             const Float4 ra = pa[e[i]];
             const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
             if (!sphere_cannot_change<false, false>(a, d2, ra.w)) a = __builtin_fminf(a, __builtin_sqrtf(d2) - ra.w);
         }
-        for (; i < n_spheres + n_boxes; ++i) {
+        _Pragma("nounroll") for (; i < n_spheres + n_boxes; ++i) {
             const uint32_t row = e[i];
             a = __builtin_fminf(a, prim_distance<K_BOX>(pa[row], pb[row], q));
         }
-        for (; i < n_spheres + n_boxes + n_crosses; ++i) {
+        _Pragma("nounroll") for (; i < n_spheres + n_boxes + n_crosses; ++i) {
             const uint32_t row = e[i];
             a = __builtin_fminf(a, prim_distance<K_CROSS>(pa[row], pb[row], q));
         }
