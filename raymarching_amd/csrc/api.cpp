@@ -624,6 +624,8 @@ int build_grid(rm_context *ctx) {
     return RM_OK;
 }
 
+int eval_points(rm_context *ctx, const float *host_xyz, uint32_t n, float *host_sd, uint32_t *host_prim, float *host_sd_march);
+
 }  // namespace
 
 extern "C" {
@@ -806,6 +808,19 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         }
     }
     ctx->have_scene = true;
+    // the one evaluation all camera rays share (trace_kernel.h: march, first_sd), with the kernels just set up
+    ctx->scene.camera_sd_known = 0u;
+    bool finite_camera = true;
+    for (int i = 0; i < 16; i++) finite_camera = finite_camera && std::isfinite(camera[i]);
+    if (finite_camera) {
+        float sd = 0.0f, sd_march = 0.0f;
+        uint32_t prim = 0;
+        if (int rc = eval_points(ctx, camera + 12, 1, &sd, &prim, &sd_march)) return rc;
+        if (std::isfinite(sd_march)) {
+            ctx->scene.camera_sd = sd_march;
+            ctx->scene.camera_sd_known = 1u;
+        }
+    }
     if (ctx->module.loaded()) {
         // The first launch of a freshly loaded kernel costs milliseconds (code upload, queue set-up): one pixel now, where
         // the reference compiles its shader, instead of inside the first frame.

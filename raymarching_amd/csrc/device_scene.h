@@ -156,6 +156,10 @@ struct SceneView {
     uint32_t n_prims;
     const float *camera;    // 16 floats of the column-major camera matrix, then the focal length
     GridView grid;
+    // Every camera ray starts at the camera's position with the same evaluation: its value, found once when the scene
+    // is uploaded (camera_sd_known = 0: not found, every ray evaluates it)
+    float camera_sd;
+    uint32_t camera_sd_known;
 };
 
 constexpr uint32_t kTileBits = 27u, kTileMask = (1u << kTileBits) - 1u;

@@ -25,7 +25,7 @@ namespace rmdev {
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
-                                      const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts]) {
+                                      const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts], int iterations) {
     bool done[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     float cap[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) cap[s] = __builtin_inff();
-    for (int it = 0; it < fr.iterations; ++it) {
+    for (int it = 0; it < iterations; ++it) {
         bool all_done = true;
 #pragma unroll
         for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
@@ -206,7 +206,15 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 #pragma unroll
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
         bool colourless[kPts];   // the ray ended on a surface the distance evaluator knows to have colour (0, 0, 0)
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless);
+        int iterations = fr.iterations;
+        if (!COUNT && r == 0 && sc.camera_sd_known != 0u && sc.camera_sd >= fr.surface_eps && iterations > 0) {
+            // Every camera ray starts with the same evaluation at the camera's position: its value was found when the scene
+            // was uploaded (SceneView::camera_sd); not below surface_eps, so no ray ends there, and the step is taken without it.
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
+            iterations--;
+        }
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
