@@ -131,8 +131,9 @@ def cpu_baseline(scene_file, kw):
 def executed_flops(c):
     """FLOPs the trace kernel executed for the counted frame: the kernel's own tally of the primitive
     evaluations it executed (11 per sphere, 9 per box, 15 per cross; lists skipped by a bound and lattice
-    crosses never visited are not in it) + 7 per march step."""
-    return c["flops_executed"] + 7 * c["march_steps"]
+    crosses never visited are not in it; nor is the camera rays' shared first evaluation, which the timed kernel
+    skips) + 7 per march step."""
+    return c["flops_executed"] - c.get("flops_shared_first", 0) + 7 * c["march_steps"]
 
 
 def recorded_traffic(workload, evaluator, kernel_mode):

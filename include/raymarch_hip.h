@@ -112,6 +112,8 @@ typedef struct rm_counters {
                               cells of the row); 5 gradient taps (lanes whose sample is shaded); 6: not a pair -- hull tests and rows folded by
                               clustered runs, per wave; 7 scene SDF calls of the
                               march loop */
+    uint64_t flops_shared_first; /* the part of flops_executed spent on the camera rays' first evaluation -- the same
+                              for every ray, found once at rm_set_scene -- which renders that do not count skip */
 } rm_counters;
 
 typedef struct rm_context rm_context;

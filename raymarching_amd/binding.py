@@ -40,7 +40,7 @@ class Counters(C.Structure):
     _fields_ = [("sdf_calls", C.c_uint64), ("march_steps", C.c_uint64), ("rays", C.c_uint64),
                 ("prims", C.c_uint64), ("prim_evals", C.c_uint64), ("lattice_prims", C.c_uint64),
                 ("flops_per_sdf", C.c_uint64), ("kernel_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("compile_ms", C.c_double), ("compiled_kernel", C.c_uint32), ("tiles_by_cost", C.c_uint32), ("march_slots", C.c_uint64), ("flops_executed", C.c_uint64), ("tile_parts", C.c_uint64), ("probe", C.c_uint64 * 16)]
+                ("compile_ms", C.c_double), ("compiled_kernel", C.c_uint32), ("tiles_by_cost", C.c_uint32), ("march_slots", C.c_uint64), ("flops_executed", C.c_uint64), ("tile_parts", C.c_uint64), ("probe", C.c_uint64 * 16), ("flops_shared_first", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

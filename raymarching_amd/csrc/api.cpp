@@ -534,6 +534,7 @@ int finish_bands(rm_context *ctx) {
         ctx->last.prim_evals = h.prim_evals;
         ctx->last.march_slots = h.march_slots;
         ctx->last.flops_executed = h.flops;
+        ctx->last.flops_shared_first = h.flops_shared_first;
         for (int i = 0; i < 16; i++) ctx->last.probe[i] = h.probe[i];
     }
     return RM_OK;

@@ -898,6 +898,7 @@ struct LaneCounts {
     unsigned long long evals;   // the exhaustive evaluator on a Menger-6 scene makes 3.4 M evaluations, 50 MFLOP, per call
     uint32_t slots;
     unsigned long long flops;
+    unsigned long long shared_first_flops;   // of `flops`: the camera rays' first evaluation where its value is known beforehand
 };
 
 }  // namespace rmdev

@@ -210,6 +210,9 @@ struct WorkCounters {
     // Lane occupancy of code regions, as pairs (lanes that executed the region x its weight, 64 x weight per wave that
     // went through it): see kProbe* in device_core.h.
     unsigned long long probe[16];
+    // the part of `flops` spent on the camera rays' first evaluation where SceneView::camera_sd is known: renders
+    // that do not count skip that evaluation (it is the same for every ray)
+    unsigned long long flops_shared_first;
 };
 
 }  // namespace rmdev

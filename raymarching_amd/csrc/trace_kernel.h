@@ -25,7 +25,8 @@ namespace rmdev {
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
-                                      const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts], int iterations) {
+                                      const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts], int iterations,
+                                      bool first_is_shared) {
     bool done[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -73,6 +74,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
                     cnt.steps++;
                     cnt.evals += work[s].evals;
                     cnt.flops += work[s].flops;
+                    if (it == 0 && first_is_shared) cnt.shared_first_flops += work[s].flops;
                 }
             }
         }
@@ -130,7 +132,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const bool in_part = lane < block * block;
     const uint32_t sx0 = (tile_x * tile_side + col) * (uint32_t)kPts;
     const uint32_t sy = tile_y * tile_side + row;
-    LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
+    LaneCounts cnt = { 0, 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-111: the camera ray of each sample
     const float AR = (float)fr.width / (float)fr.height;
@@ -207,14 +209,15 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         for (int s = 0; s < kPts; ++s) at[s] = p[s];
         bool colourless[kPts];   // the ray ended on a surface the distance evaluator knows to have colour (0, 0, 0)
         int iterations = fr.iterations;
-        if (!COUNT && r == 0 && sc.camera_sd_known != 0u && sc.camera_sd >= fr.surface_eps && iterations > 0) {
+        const bool first_is_shared = r == 0 && sc.camera_sd_known != 0u && sc.camera_sd >= fr.surface_eps && iterations > 0;
+        if (!COUNT && first_is_shared) {
             // Every camera ray starts with the same evaluation at the camera's position: its value was found when the scene
             // was uploaded (SceneView::camera_sd); not below surface_eps, so no ray ends there, and the step is taken without it.
 #pragma unroll
             for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
             iterations--;
         }
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations);
+        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared);
         if (r == 0) {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
@@ -334,9 +337,9 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 
     if (COUNT) {
         // per wave: its lanes' sums, then one atomic per counter
-        unsigned long long sums[6] = { cnt.sdf, cnt.steps, cnt.rays, cnt.evals, cnt.slots, cnt.flops };
+        unsigned long long sums[7] = { cnt.sdf, cnt.steps, cnt.rays, cnt.evals, cnt.slots, cnt.flops, cnt.shared_first_flops };
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 7; ++i) {
             unsigned long long v = sums[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             sums[i] = v;
@@ -348,6 +351,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             atomicAdd(&counters->prim_evals, sums[3]);
             atomicAdd(&counters->march_slots, sums[4]);
             atomicAdd(&counters->flops, sums[5]);
+            atomicAdd(&counters->flops_shared_first, sums[6]);
         }
     }
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ void trace_refill_body(const SceneView &sc, const Fra
     const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
     const uint32_t total = 1u << (w_log2 + h_log2);
     float *parked = reinterpret_cast<float *>(lds.park);   // [kParkedMax][x, y, z, sample address]
-    LaneCounts cnt = { 0, 0, 0, 0, 0, 0 };
+    LaneCounts cnt = { 0, 0, 0, 0, 0, 0, 0 };
 
     // ---- render::pixel, render.cpp:82-101: what all samples share
     const float AR = (float)fr.width / (float)fr.height;
