@@ -61,10 +61,30 @@ std::string default_cache_dir() {
     return "";
 }
 
+// $RM_JIT_EXTRA: further compiler options, separated by blanks (for sweeps of code generation settings; part of the
+// cache key, never of the arithmetic: -ffp-contract=off and the rounding options above stay)
+std::vector<std::string> extra_options() {
+    std::vector<std::string> out;
+    if (const char *env = std::getenv("RM_JIT_EXTRA")) {
+        std::string word;
+        for (const char *c = env;; c++) {
+            if (*c == ' ' || *c == '\0') {
+                if (!word.empty()) out.push_back(word);
+                word.clear();
+                if (*c == '\0') break;
+            } else {
+                word += *c;
+            }
+        }
+    }
+    return out;
+}
+
 // FNV-1a over the source and the embedded headers: names a code object file.  The file also holds
 // the full key text, compared on load, so a hash collision costs a recompile, never a wrong kernel.
 std::string cache_key_text(const std::string &source) {
     std::string key = source;
+    for (const std::string &o : extra_options()) key += "\n//@option " + o;
     for (unsigned i = 0; i < kEmbeddedHeaderCount; i++) {
         key += "\n//@";
         key += kEmbeddedHeaders[i].name;
@@ -137,9 +157,11 @@ CodeObject build_code_object(const std::string &source, std::string &log) {
         log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
         return nullptr;
     }
-    const char *options[] = { "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
-                              "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt" };
-    r = hiprtcCompileProgram(prog, (int)(sizeof options / sizeof options[0]), options);
+    std::vector<const char *> options = { "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+                                          "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt" };
+    const std::vector<std::string> extra = extra_options();
+    for (const std::string &o : extra) options.push_back(o.c_str());
+    r = hiprtcCompileProgram(prog, (int)options.size(), options.data());
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         (void)hiprtcGetProgramLogSize(prog, &n);
