@@ -306,6 +306,22 @@ def main():
         for i in range(2 * F):
             frame(i, i == 2 * F - 1)
         drain()
+    # Before the W warm-up frames: the GPU under load long enough to reach its steady clocks.  The tile timing above runs
+    # one frame at a time with the GPU idle in between; 20 timed frames right after 5 warm-up frames measure 0.545 ms per
+    # default frame, after 50 or more 0.515 ms -- the rate of every longer run.  The same count on every rank (the
+    # frames go through the collective); a lone process goes on until 40 ms have passed.
+    pre_roll = 64
+    t_pre = time.perf_counter()
+    for i in range(pre_roll):
+        frame(i, i == pre_roll - 1)
+    drain()
+    if not group:
+        while time.perf_counter() - t_pre < 0.040 and pre_roll < 4096:
+            for i in range(F):
+                frame(i, i == F - 1)
+            drain()
+            pre_roll += F
+    gathered.clear()
     for i in range(a.warmup):
         frame(i, i == a.warmup - 1)
     drain()
@@ -501,7 +517,7 @@ def main():
                                   else "every sample (the reference's full work)",
                        "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
                        "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
-                       "frames_in_flight": F, "frames_per_gather": G,
+                       "frames_in_flight": F, "frames_per_gather": G, "untimed_frames_before_warmup": pre_roll,
                        "sharding": ("single launch" + (", sent through a one-rank RCCL gather" if group else "")) if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
             "roofline": {
                 "bound": "valu_fp32", "kernel": "rm_trace (generated for the scene)" if a.kernel_mode == "compiled" else "trace_kernel (record walker)", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
