@@ -183,9 +183,11 @@ def main():
     # with 20 timed frames the count makes no difference).
     split = max(world, a.emulate_share)
     F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split < 8 else 16)
-    # frames per collective (one measured best on one GPU: queueing a gather costs the host ~0.03 ms, less than a
-    # rank's share of a default frame takes to render at N = 8, and frames gathered together wait for each other)
-    G = a.frames_per_gather if a.frames_per_gather > 0 else 1
+    # frames per collective: queueing a gather costs the host ~0.03 ms, and frames gathered together wait for each other.
+    # One per frame up to four ranks; from eight on a rank's share of a default frame takes 0.065 ms to render, the host
+    # is the slower side, and two frames share a collective (rank 0's eighth through a one-rank gather, ms per frame:
+    # 20 timed frames 0.127 against 0.150, 400 timed frames 0.104 against 0.100)
+    G = a.frames_per_gather if a.frames_per_gather > 0 else (1 if split < 8 else 2)
     if F % G:
         raise SystemExit("--frames-in-flight must be a multiple of --frames-per-gather")
     rs, set_scene_s = [], 0.0
