@@ -548,7 +548,7 @@ int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned ch
 
 // Builds the cell grid over the root's long runs (device_scene.h: GridView) on the device; leaves ctx->scene.grid empty
 // if the scene has no such runs.  The box: around the runs' primitives, a fifth of its longest side wider on every
-// side (camera and shadow rays start and end near the scene); about 1024 cells per table row, four million at most.
+// side (camera and shadow rays start and end near the scene); about 4096 cells per table row, sixteen million at most.
 int build_grid(rm_context *ctx) {
     rmdev::GridView &g = ctx->scene.grid;
     g = rmdev::GridView{};
@@ -583,11 +583,12 @@ int build_grid(rm_context *ctx) {
         side[k] += 2.0 * pad;
         volume *= side[k];
     }
-    // cells per table row: finer cells list fewer rows each (measured on the 1024-object scenes, ms per frame: 256 cells
-    // per row 28.4 / 7.8, 1024 22.8 / 6.3, 4096 23.2 / 5.9); $RM_GRID_CELLS_PER_ROW overrides it for such sweeps
-    double per_row = 1024.0;
+    // cells per table row: finer cells list fewer rows each.  Measured on the 1024-object scene / its wide variant with
+    // the box above, ms per frame: 1024 cells per row 20.4 / 6.5, 2048 19.0 / 6.3, 4096 17.9 / 5.9, 8192 17.4 / 5.8,
+    // 16384 16.8 / 5.7 (16.8 M cells: a quarter of a gigabyte of headers); $RM_GRID_CELLS_PER_ROW overrides it for such sweeps
+    double per_row = 4096.0;
     if (const char *env = std::getenv("RM_GRID_CELLS_PER_ROW")) per_row = std::max(1.0, std::atof(env));
-    const double target = std::min(double(1u << 22), std::max(4096.0, per_row * (double)n_rows));
+    const double target = std::min(double(1u << 24), std::max(4096.0, per_row * (double)n_rows));
     const double cell = std::cbrt(volume / target);
     if (!(cell > 0.0) || !std::isfinite(cell)) return RM_OK;
     uint64_t n_cells = 1;
