@@ -640,6 +640,11 @@ __device__ __forceinline__ float lattice_row(const float *T, const uint32_t *ONE
 // evaluated which cell).  Must be called from control flow that is uniform among the executing
 // lanes; lanes that have left the walk earlier simply are not among the workers.
 
+// what handing one row round costs, in cells (the broadcast of the owner's operands, the LDS exchange of the maxima)
+#ifndef RM_ROW_COOP_COST
+#define RM_ROW_COOP_COST 6
+#endif
+
 template <int AXIS, bool COUNT = false>
 __device__ __forceinline__ float lattice_rows(bool active, const float *T, const uint32_t *ONES, int n, float pt, float h, float d1,
                                               float d2, uint32_t fixed_ones, float run) {
@@ -658,7 +663,7 @@ __device__ __forceinline__ float lattice_rows(bool active, const float *T, const
         const unsigned long long workers = __builtin_amdgcn_ballot_w64(true);
         const int n_workers = __builtin_popcountll(workers), n_rows = __builtin_popcountll(rows);
         // cells per lane: n when every owner walks its own row; per row a share of n plus the exchange otherwise
-        if (n_rows * ((n + n_workers - 1) / n_workers + 6) < n) {
+        if (n_rows * ((n + n_workers - 1) / n_workers + RM_ROW_COOP_COST) < n) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(workers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)workers, 0u));
             const int lane = (int)(threadIdx.x & 63u);
             float *slot = wave_slot();
