@@ -7,7 +7,18 @@
 
 #include "device_core.h"
 
+#ifndef RM_SPREAD_SHADOWS
+#define RM_SPREAD_SHADOWS 1   // 0: the shadow rays of a tile part's samples march one light after the other on the sample's lane
+#endif
+
 namespace rmdev {
+
+// the value lane `from` of the wave holds; `from` must be an executing lane (ds_bpermute returns 0 for the others), so
+// this is called only where the whole wave executes
+__device__ __forceinline__ float from_lane(float v, uint32_t from) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(from << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ V3 from_lane(V3 v, uint32_t from) { return v3(from_lane(v.x, from), from_lane(v.y, from), from_lane(v.z, from)); }
 
 // scene::surface (scene.cpp:34-42) for the lane's two samples in lockstep: advances p[s]
 // along ray[s] while sample s is live; at[s] is the point of its last SDF evaluation (whose
@@ -81,6 +92,18 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     }
 }
 
+// scene::lighting / scene::shadow, scene.cpp:45-62: the shadow ray from a hit to a light, and what lets its march stop
+// once it is past the light (see march)
+__device__ __forceinline__ void shadow_ray(V3 light, V3 hit, V3 normal, float lift, const FrameView &fr, V3 &p, V3 &ray, float &to_light,
+                                           float &past_light) {
+    ray = normalize3(light - hit);
+    p = hit + normal * lift;
+    to_light = fr.skip_unlit ? dot3(light - p, ray) : __builtin_inff();
+    const float scale = __builtin_fabsf(light.x) + __builtin_fabsf(light.y) + __builtin_fabsf(light.z) +
+                        __builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __builtin_fabsf(to_light);
+    past_light = 0.01f + (1e-4f + 4e-7f * (float)fr.iterations) * scale;
+}
+
 // A workgroup is n x n waves (n = 1, 2 or 3, from the launch) and renders one tile of 8n x 8n samples (16n x 8n with two
 // samples per lane), each wave an 8 x 8 block of it.
 // kPts = 2: each lane two horizontally adjacent samples that march in lockstep -- halves the scalar-unit cost per
@@ -97,6 +120,13 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
 // side, sixteenth q the (q & 3, q >> 2) sub-tile of a quarter of the side; the workgroup's waves split the sub-tile
 // among them as they split a tile, so a wave renders 4 x 4 or 2 x 2 samples on its first 16 or 4 lanes and waits
 // only for those.
+//
+// Shadow rays of a part, spread over the wave: a part exists because its samples' rays are the longest of the frame,
+// and the shadow rays of one sample (scene::lighting's loop, scene.cpp:52-62) do not depend on each other.  With B
+// samples on the first B lanes and G = min(64 / B, lights) groups of B lanes, lane g * B + s marches the ray of
+// sample s to light `first + g` of the round, all G at once, and the sample's own lane then adds the contributions
+// up in the order of the lights, as the reference's loop does.  The serial path of a sample goes from 1 + L marches
+// to 1 + ceil(L / G); every ray is the same ray, so the frame and the work counters do not change.
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples,
                                            WorkCounters *__restrict__ counters) {
@@ -130,6 +160,18 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t col = part_x + wave_x * block + (lane & (block - 1u));
     const uint32_t row = part_y + wave_y * block + ((lane >> (3u - split_log2)) & (block - 1u));
     const bool in_part = lane < block * block;
+    // shadow rays spread over the wave's idle lanes (wave-uniform; see above)
+    const uint32_t part_lanes = block * block;                                // B: 16 or 4 in a part
+    const bool spread = RM_SPREAD_SHADOWS != 0 && kPts == 1 && part != 0u && sc.n_lights >= 2u;
+    const uint32_t groups = spread ? (64u / part_lanes < sc.n_lights ? 64u / part_lanes : sc.n_lights) : 1u;   // G
+    const uint32_t rounds = spread ? (sc.n_lights + groups - 1u) / groups : sc.n_lights;
+    // the lane of the sample whose shadow rays this lane marches, and which of the round's lights it takes: found anew
+    // where they are needed (the empty asm keeps the compiler from holding them in registers across the marches)
+    const auto lane_now = [] {
+        uint32_t l = threadIdx.x & 63u;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
     const uint32_t sx0 = (tile_x * tile_side + col) * (uint32_t)kPts;
     const uint32_t sy = tile_y * tile_side + row;
     LaneCounts cnt = { 0, 0, 0, 0, 0, 0, 0 };
@@ -162,8 +204,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         lit[s] = live[s];
     }
 
-    // ---- scene::raymarch, scene.cpp:26-32.  Ray 0 is the camera ray; ray 1 + l is the shadow
-    // ray to light l (scene::lighting / scene::shadow, scene.cpp:45-62).  One march instance.
+    // ---- scene::raymarch, scene.cpp:26-32: the camera ray, then one shadow ray per light
+    // (scene::lighting / scene::shadow, scene.cpp:45-62).
     V3 hit[kPts], normal[kPts], p[kPts], ray[kPts], at[kPts];
     float lighting[kPts], to_light[kPts], past_light[kPts];
     uint32_t prim[kPts];
@@ -175,10 +217,11 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
         prim[s] = kNoPrim;
     }
     const float lift = fr.surface_eps + fr.offset_eps;
-#pragma unroll 1
-    for (uint32_t r = 0; r <= sc.n_lights; ++r) {
-        V3 light = v3(0.0f, 0.0f, 0.0f);
-        if (r == 0) {
+    // The camera ray and what follows it at the hit (colour, normal), then the shadow rays.  Two march instances: the
+    // camera rays need neither the test against a light nor the cap of a shadow ray's first step.
+    do {
+        bool colourless[kPts];   // the ray ended on a surface the distance evaluator knows to have colour (0, 0, 0)
+        {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) {
                 const uint32_t sx = sx0 + (uint32_t)s;
@@ -192,33 +235,20 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 to_light[s] = __builtin_inff();
                 past_light[s] = 0.0f;
             }
-        } else {
-            const RowWords lp = ((ConstRows)sc.lights)[r - 1];
-            light = v3(lp[0], lp[1], lp[2]);
 #pragma unroll
-            for (int s = 0; s < kPts; ++s) {
-                ray[s] = normalize3(light - hit[s]);
-                p[s] = hit[s] + normal[s] * lift;
-                to_light[s] = fr.skip_unlit ? dot3(light - p[s], ray[s]) : __builtin_inff();
-                const float scale = __builtin_fabsf(light.x) + __builtin_fabsf(light.y) + __builtin_fabsf(light.z) +
-                                    __builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(to_light[s]);
-                past_light[s] = 0.01f + (1e-4f + 4e-7f * (float)fr.iterations) * scale;
+            for (int s = 0; s < kPts; ++s) at[s] = p[s];
+            int iterations = fr.iterations;
+            const bool first_is_shared = sc.camera_sd_known != 0u && sc.camera_sd >= fr.surface_eps && iterations > 0;
+            if (!COUNT && first_is_shared) {
+                // Every camera ray starts with the same evaluation at the camera's position: its value was found when the scene
+                // was uploaded (SceneView::camera_sd); not below surface_eps, so no ray ends there, and the step is taken without it.
+#pragma unroll
+                for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
+                iterations--;
             }
+            march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared);
         }
-#pragma unroll
-        for (int s = 0; s < kPts; ++s) at[s] = p[s];
-        bool colourless[kPts];   // the ray ended on a surface the distance evaluator knows to have colour (0, 0, 0)
-        int iterations = fr.iterations;
-        const bool first_is_shared = r == 0 && sc.camera_sd_known != 0u && sc.camera_sd >= fr.surface_eps && iterations > 0;
-        if (!COUNT && first_is_shared) {
-            // Every camera ray starts with the same evaluation at the camera's position: its value was found when the scene
-            // was uploaded (SceneView::camera_sd); not below surface_eps, so no ray ends there, and the step is taken without it.
-#pragma unroll
-            for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
-            iterations--;
-        }
-        march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared);
-        if (r == 0) {
+        {
 #pragma unroll
             for (int s = 0; s < kPts; ++s) hit[s] = p[s];
             // the Surface scene::surface returned: colour of the last evaluation -- from the colour-tracking walk, unless
@@ -303,14 +333,58 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             const float two_h = 2 * hh;
 #pragma unroll
             for (int s = 0; s < kPts; ++s) normal[s] = normalize3(v3(g[s][0] / two_h, g[s][1] / two_h, g[s][2] / two_h));
-        } else {
-#pragma unroll
-            for (int s = 0; s < kPts; ++s) {
-                const bool shadowed = dot3(light - p[s], ray[s]) > 0;
-                if (!shadowed) lighting[s] += dot3(normal[s], ray[s]);
+            if (spread) {
+                // every lane takes the hit, the normal and the lit flag of the sample whose shadow rays it will march
+                // (lanes of the part itself: their own)
+                const uint32_t source = lane_now() & (part_lanes - 1u);
+                hit[0] = from_lane(hit[0], source);
+                normal[0] = from_lane(normal[0], source);
+                lit[0] = from_lane(lit[0] ? 1.0f : 0.0f, source) != 0.0f;
             }
         }
-    }
+#pragma unroll 1
+        for (uint32_t r = 1; r <= rounds; ++r) {
+            V3 light = v3(0.0f, 0.0f, 0.0f);
+            bool marching[kPts];   // the rays of this round
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) marching[s] = lit[s];
+            if (spread) {
+                // the lane's own light of this round (hit, normal and lit are its source sample's by now)
+                const uint32_t group = lane_now() / part_lanes, mine = (r - 1u) * groups + group;
+                const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
+                const V3 own = v3(lp.x, lp.y, lp.z);
+                marching[0] = lit[0] && group < groups && mine < sc.n_lights;
+                shadow_ray(own, hit[0], normal[0], lift, fr, p[0], ray[0], to_light[0], past_light[0]);
+            } else {
+                const RowWords lp = ((ConstRows)sc.lights)[r - 1];
+                light = v3(lp[0], lp[1], lp[2]);
+#pragma unroll
+                for (int s = 0; s < kPts; ++s) shadow_ray(light, hit[s], normal[s], lift, fr, p[s], ray[s], to_light[s], past_light[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < kPts; ++s) at[s] = p[s];
+            bool colourless_unused[kPts];
+            march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, marching, to_light, past_light, cnt, colourless_unused, fr.iterations, false);
+            if (spread) {
+                const uint32_t now = lane_now(), source = now & (part_lanes - 1u), mine = (r - 1u) * groups + now / part_lanes;
+                const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
+                const float unshadowed = dot3(v3(lp.x, lp.y, lp.z) - p[0], ray[0]) > 0 ? 0.0f : 1.0f;
+                const float towards = dot3(normal[0], ray[0]);
+                // the sample's lane adds its rays' contributions in the order of the lights (scene.cpp:55-59)
+                for (uint32_t g = 0; g < groups && (r - 1u) * groups + g < sc.n_lights; ++g) {
+                    const float open = from_lane(unshadowed, g * part_lanes + source);
+                    const float term = from_lane(towards, g * part_lanes + source);
+                    if (in_part && open != 0.0f) lighting[0] += term;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < kPts; ++s) {
+                    const bool shadowed = dot3(light - p[s], ray[s]) > 0;
+                    if (!shadowed) lighting[s] += dot3(normal[s], ray[s]);
+                }
+            }
+        }
+    } while (false);
 
     // Whole pixels in the workgroup (see FrameView::pixels_f32): the samples meet in LDS and the wave that arrives last
     // adds them up, every pixel in the reference's order (render.cpp:103-112: i, the column, outer; j inner).
