@@ -221,6 +221,26 @@ __device__ __forceinline__ bool sphere_bound_wanted(const V3 (&p)[NP], const flo
     return __builtin_amdgcn_ballot_w64(need) != 0;
 }
 
+// One test in front of several children of a union (values folded with min): the children's bounding spheres and
+// boxes all lie in the box (centre c, half sizes H), and every one of their values is at least the largest-coordinate
+// excess m of p over that box -- a sphere's |p - centre| - r and a box's max(|d| - h) both are, in exact arithmetic.
+// The values the children would fold are rounded: each is at least m - 2^-20 (|m| + H + the child's own size), and m as
+// computed here is within 2^-22 (|m| + H) of the exact one.  The host passes H enlarged by 3e-6 of (the largest H + the
+// largest child size), and 3e-6 |m| is taken off here, so `false` proves that no child can lower any lane's accumulator
+// (NaNs answer `true`).  Per wave, like the other bound tests: if one lane needs the children, all evaluate them.
+template <int NP>
+__device__ __forceinline__ bool group_wanted(const V3 (&p)[NP], const float (&acc)[NP], float cx, float cy, float cz, float hx, float hy,
+                                             float hz) {
+    bool need = false;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p[n].x - cx) - hx, __builtin_fabsf(p[n].y - cy) - hy),
+                                        __builtin_fabsf(p[n].z - cz) - hz);
+        need = need || !(__builtin_fmaf(__builtin_fabsf(m), -3e-6f, m) >= acc[n]);
+    }
+    return __builtin_amdgcn_ballot_w64(need) != 0;
+}
+
 // Folds one child value per point into the accumulators (see device_scene.h).
 template <int NP, bool TRACK>
 __device__ __forceinline__ void fold_value(uint32_t flags, const float (&v)[NP], const uint32_t (&vprim)[NP],
