@@ -84,7 +84,8 @@ uint32_t parse_children(const std::vector<Rec> &recs, uint32_t i, std::vector<It
 // small steps (the tunnels of a sponge): there the accumulator is tiny by the time the spheres' turn comes, and one test
 // rules them all out; in front, the accumulator is still the distance to the floor and the walls and rules out little.
 // Shipped frame, ms per frame in flight, same GPU: 0.492 as before, 0.489 with the common test at the spheres' old place,
-// 0.466 with the spheres after the lists, 0.451 with both; 4K 8.83 -> 8.09.
+// 0.466 with the spheres after the lists, 0.451 with both; 4K 8.83 -> 8.09.  (An outer test around the lists and the
+// members together, for points far from all of them, measured slower: 0.460 against 0.449, 4K 8.25 against 8.08.)
 // $RM_GROUP_TESTS selects the variant for such A/B runs (the generated source, and with it the cache key, differs):
 // 0 neither; 1 the common test at the first member's place; 2 the same with box-bounded lists as members too; 3 (default)
 // members last, behind the common test; 4 members last without it.
