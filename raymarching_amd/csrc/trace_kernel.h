@@ -32,8 +32,8 @@ __device__ __forceinline__ V3 from_lane(V3 v, uint32_t from) { return v3(from_la
 // back by more than the roundings, because the scene SDF is 1-Lipschitz (see `cap` below), so after a step
 // of length sd its value is at least -roundings.  past_light covers both: 1.8e-7 of the coordinates'
 // magnitude per step for the roundings of p (three components, half an ulp each), 3e-5 of it for the SDF.
-// Camera rays pass to_light = +inf.
-template <class Scene, int kPts, bool COUNT>
+// Camera rays have no light to pass: SHADOW = false leaves the test out (to_light and past_light are not read).
+template <class Scene, int kPts, bool COUNT, bool SHADOW>
 __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
                                       const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts], int iterations,
@@ -78,8 +78,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
                 p[s] = p[s] + ray[s] * sd[s];
                 cap[s] = sd[s] + __builtin_fabsf(sd[s]) * 1.00001f +
                          4e-6f * (__builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(sd[s]));
-                to_light[s] -= sd[s];
-                done[s] = sd[s] < fr.surface_eps || to_light[s] < -past_light[s];
+                if (SHADOW) to_light[s] -= sd[s];
+                done[s] = sd[s] < fr.surface_eps || (SHADOW && to_light[s] < -past_light[s]);
                 if (COUNT) {
                     cnt.sdf++;
                     cnt.steps++;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     // ---- scene::raymarch, scene.cpp:26-32: the camera ray, then one shadow ray per light
     // (scene::lighting / scene::shadow, scene.cpp:45-62).
     V3 hit[kPts], normal[kPts], p[kPts], ray[kPts], at[kPts];
-    float lighting[kPts], to_light[kPts], past_light[kPts];
+    float lighting[kPts], to_light[kPts] = {}, past_light[kPts] = {};
     uint32_t prim[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -232,8 +232,6 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 const float x = lerp1(p1x, p2x, uvx);
                 p[s] = origin;
                 ray[s] = camera_view(cam, normalize3(v3(x, y, -1.0f)), 0.0f);
-                to_light[s] = __builtin_inff();
-                past_light[s] = 0.0f;
             }
 #pragma unroll
             for (int s = 0; s < kPts; ++s) at[s] = p[s];
@@ -246,7 +244,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
                 iterations--;
             }
-            march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared);
+            march<Scene, kPts, COUNT, false>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared);
         }
         {
 #pragma unroll
@@ -364,7 +362,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 #pragma unroll
             for (int s = 0; s < kPts; ++s) at[s] = p[s];
             bool colourless_unused[kPts];
-            march<Scene, kPts, COUNT>(sc, lds, fr, p, ray, at, marching, to_light, past_light, cnt, colourless_unused, fr.iterations, false);
+            march<Scene, kPts, COUNT, true>(sc, lds, fr, p, ray, at, marching, to_light, past_light, cnt, colourless_unused, fr.iterations, false);
             if (spread) {
                 const uint32_t now = lane_now(), source = now & (part_lanes - 1u), mine = (r - 1u) * groups + now / part_lanes;
                 const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
