@@ -1,11 +1,13 @@
 #!/bin/bash
 # Collects the round's profiles on the GPU box: bash tools/profile_round.sh <out dir under gpurun_out>
 # (bench lines of every workload, rocprofv3 kernel statistics of the default bench, TCC traffic counters).
+# $PART=1: bench lines, rehearsal and lane utilisation only; $PART=2: rocprofv3 passes only (each half fits one GPU call).
 set -e -o pipefail
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/${1:-profile}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p "$OUT"
 cd "$REPO"
+if [ "${PART:-1}" != 2 ]; then
 timeout -k 10 300 python3 -u bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 bash tools/emulate_scaling.sh > "$OUT/emulate_scaling.txt" 2>&1
 timeout -k 10 300 python3 tools/march_util.py default uhd menger2 closeup6 synthetic synthetic_wide > "$OUT/march_util.txt" 2>/dev/null
@@ -13,6 +15,8 @@ for w in menger2 uhd closeup6 synthetic synthetic_wide; do
     steps=10; [ $w = menger2 ] && steps=200   # a menger2 frame is 0.1 ms: few frames time the launch, not the frame
     timeout -k 10 300 python3 -u bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
 done
+fi
+[ "${PART:-2}" = 1 ] && { echo done; exit 0; }
 cd /tmp
 export TMPDIR=/tmp
 # one frame in flight here, so that every rm_trace launch runs alone and the statistics' average duration is
