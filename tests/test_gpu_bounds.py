@@ -85,6 +85,57 @@ def test_nested_lists_with_long_runs(rm, oracle, renderer):
     _check(rm, oracle, renderer, spec, _points(rng, spec, 8000, spread))
 
 
+@pytest.mark.parametrize("seed,shift", [(31, 0.0), (32, 0.0), (33, 3000.0), (34, -70000.0)])
+def test_spheres_of_the_root_behind_their_common_box_test(rm, oracle, renderer, seed, shift):
+    """The root union's spheres and sphere-bounded lists are folded last, behind one test of the point against the box
+    around them.  Points where that test is closest to wrong: the floor's distance equals the distance to the box's
+    face, on the axis through a sphere's centre (the sphere's value equals the box excess there), a few ulps either
+    side; the whole scene also far from the origin, where roundings are largest."""
+    rng = np.random.default_rng(seed)
+    zero = (0, 0, 0)
+
+    def ball():
+        return (SPHERE, 0, 0, (shift + rng.uniform(-30, 30), rng.uniform(0.5, 12), rng.uniform(-30, 30)), (rng.uniform(0.3, 6), 0, 0),
+                rng.uniform(0.1, 1, 3))
+
+    loose = [ball() for _ in range(int(rng.integers(2, 4)))]           # fewer than four: records of their own, not a run
+    wrapped = [ball() for _ in range(int(rng.integers(1, 6)))]         # each the only child of a list
+    balls = loose + wrapped
+    star = [(LIST, DIFFERENCE, 2, zero, zero, zero), (SPHERE, 0, 0, (shift + 8.0, 5.0, -12.0), (5, 0, 0), (0, 0, 1)),
+            (SPHERE, 0, 0, (shift + 11.0, 6.0, -12.0), (3, 0, 0), (0, 0, 1))]
+    holed = [(LIST, DIFFERENCE, 3, zero, zero, zero), (BOX, 0, 0, (shift - 45.0, 10.0, 40.0), (20, 20, 20), (1, 1, 1)),
+             (CROSS, 0, 0, (shift - 45.0, 10.0, 40.0), (6, 6, 6), (1, 1, 1)), (SPHERE, 0, 0, (shift - 45.0, 22.0, 40.0), (4, 0, 0), (1, 1, 1))]
+    spec = [(LIST, UNION, 4 + len(balls), zero, zero, zero)]
+    spec += [(LIST, COMPLEMENT, 1, zero, zero, zero), (BOX, 0, 0, (shift, 0, 0), (400, 400, 400), zero)]
+    spec += [(BOX, 0, 0, (shift, -1.0, 0.0), (300, 2, 300), (0.5, 0.5, 0.5))]
+    spec += loose + star + holed
+    for w in wrapped:
+        spec += [(LIST, UNION, 1, zero, zero, zero), w]
+
+    class AsScene:
+        def nodes(self):
+            nodes = _nodes(rm.Node, spec)
+            return (rm.Node * len(nodes))(*nodes)
+    assert "group_wanted" in rm.kernel_source(AsScene())   # the scene does exercise the common test
+    spread_pts = _points(rng, spec, 3000, 60.0)
+    spread_pts[1000:] += np.float32([shift, 0, 0])   # the first third lies at the primitives, wherever they are
+    pts = [spread_pts]
+    for (_, _, _, c, size, _) in balls + [star[1]]:
+        c = np.asarray(c, np.float64)
+        for axis, sign in ((0, 1), (0, -1), (2, 1), (2, -1)):
+            q = c.astype(np.float32)
+            q[axis] = np.float32(c[axis] + sign * (size[0] + c[1]))   # as far from the sphere as the floor is below
+            for ulps in range(-6, 7):
+                v = q.copy()
+                for _ in range(abs(ulps)):
+                    v[axis] = np.nextafter(v[axis], np.float32(np.inf if ulps > 0 else -np.inf))
+                pts.append(v[None, :])
+                w = v.copy()
+                w[1] = np.nextafter(w[1], np.float32(np.inf if ulps % 2 else -np.inf))
+                pts.append(w[None, :])
+    _check(rm, oracle, renderer, spec, np.concatenate(pts).astype(np.float32))
+
+
 def test_identical_and_degenerate_rows(rm, oracle, renderer):
     """Runs whose rows coincide (zero-extent bounding boxes, Morton keys all equal) or have zero size."""
     rng = np.random.default_rng(12)
