@@ -30,6 +30,27 @@ def test_twenty_lights(rm, oracle, renderer):
     assert gpu.tobytes() == cpu.tobytes()
 
 
+@pytest.mark.parametrize("n_lights", [3, 5, 18])
+def test_split_tiles_march_their_shadow_rays_side_by_side(rm, oracle, renderer, n_lights):
+    """In the parts of a split tile (the longest tiles of a cost-ordered frame) the shadow rays of a sample march on
+    different lanes of the wave, several lights per round, and the sample's lane adds the contributions up in the order
+    of the lights (scene.cpp:52-62): 3 lights fit one round, 5 take two rounds in a quarter (four groups of 16 lanes)
+    with the last round short, 18 two rounds in a sixteenth too.  Same frame as the oracle's, parts or not."""
+    rng = np.random.default_rng(40 + n_lights)
+    lights = "".join(f"Light {x:.3f} {y:.3f} {z:.3f}\n" for x, y, z in rng.uniform([-50, 30, -80], [50, 60, 0], (n_lights - 2, 3)))
+    text = open(scene_path("default.txt")).read() + "\n" + lights
+    kw = dict(width=160, height=100, kernel=2)
+    cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(text=text))
+    assert renderer.render_f32().tobytes() == cpu.tobytes()            # natural order, whole tiles
+    for _ in range(2):
+        again = renderer.render_f32()
+        c = renderer.counters()
+        assert c["tiles_by_cost"] == 1 and (c["tile_parts"] > 0) == (renderer.kernel_mode == "compiled")
+        assert again.tobytes() == cpu.tobytes()
+
+
 @pytest.mark.parametrize("kw", [dict(width=40, height=30, kernel=5), dict(width=45, height=31, kernel=4), dict(width=21, height=13, kernel=8),
                                 dict(width=3, height=2, kernel=4), dict(width=1, height=1, kernel=3), dict(width=257, height=1, kernel=2),
                                 dict(width=3, height=129, kernel=1), dict(width=64, height=48, kernel=2, iterations=7),
