@@ -90,7 +90,8 @@ def test_spheres_of_the_root_behind_their_common_box_test(rm, oracle, renderer, 
     """The root union's spheres and sphere-bounded lists are folded last, behind one test of the point against the box
     around them.  Points where that test is closest to wrong: the floor's distance equals the distance to the box's
     face, on the axis through a sphere's centre (the sphere's value equals the box excess there), a few ulps either
-    side; the whole scene also far from the origin, where roundings are largest."""
+    side, and nearer by shares from 1e-6 to 1e-2; the whole scene also far from the origin, where roundings are largest.
+    (Checked once against a build whose test accepted points 1e-4 too early: it fails here.)"""
     rng = np.random.default_rng(seed)
     zero = (0, 0, 0)
 
@@ -117,22 +118,36 @@ def test_spheres_of_the_root_behind_their_common_box_test(rm, oracle, renderer, 
             nodes = _nodes(rm.Node, spec)
             return (rm.Node * len(nodes))(*nodes)
     assert "group_wanted" in rm.kernel_source(AsScene())   # the scene does exercise the common test
-    spread_pts = _points(rng, spec, 3000, 60.0)
-    spread_pts[1000:] += np.float32([shift, 0, 0])   # the first third lies at the primitives, wherever they are
-    pts = [spread_pts]
-    for (_, _, _, c, size, _) in balls + [star[1]]:
+    spread_pts = _points(rng, spec, 3072, 60.0)
+    spread_pts[1024:] += np.float32([shift, 0, 0])   # the first third lies at the primitives, wherever they are
+    # The test is made per wave (one lane that needs the spheres makes all evaluate them), so probe points of one kind
+    # fill whole workgroups of the evaluation kernel (256 points): a wave that skips wrongly is then not covered
+    # up by a neighbour that needs the spheres anyway.
+    kinds = {}
+    members = balls + [star[1]]
+    for axis, sign in ((0, 1), (0, -1), (2, 1), (2, -1)):
+        # the sphere that reaches furthest this way: the box's face is its extreme point, so along its axis the
+        # sphere's value equals the excess over the box (elsewhere the point would lie inside the box)
+        (_, _, _, c, size, _) = max(members, key=lambda m: sign * m[3][axis] + m[4][0])
         c = np.asarray(c, np.float64)
-        for axis, sign in ((0, 1), (0, -1), (2, 1), (2, -1)):
-            q = c.astype(np.float32)
-            q[axis] = np.float32(c[axis] + sign * (size[0] + c[1]))   # as far from the sphere as the floor is below
-            for ulps in range(-6, 7):
+        q = c.astype(np.float32)
+        q[axis] = np.float32(c[axis] + sign * (size[0] + c[1]))   # as far from the sphere as the floor is below
+        for ulps in range(-6, 7):
+            v = q.copy()
+            for _ in range(abs(ulps)):
+                v[axis] = np.nextafter(v[axis], np.float32(np.inf if ulps > 0 else -np.inf))
+            kinds.setdefault(("ulps", ulps), []).append(v)
+            w = v.copy()
+            w[1] = np.nextafter(w[1], np.float32(np.inf if ulps % 2 else -np.inf))
+            kinds.setdefault(("ulps", ulps), []).append(w)
+        # and a little nearer or further: a test that skipped the spheres too early by any of these shares would
+        # lose the sphere where it is the nearer surface
+        for share in (1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 1e-2):
+            for side in (-1, 1):
                 v = q.copy()
-                for _ in range(abs(ulps)):
-                    v[axis] = np.nextafter(v[axis], np.float32(np.inf if ulps > 0 else -np.inf))
-                pts.append(v[None, :])
-                w = v.copy()
-                w[1] = np.nextafter(w[1], np.float32(np.inf if ulps % 2 else -np.inf))
-                pts.append(w[None, :])
+                v[axis] = np.float32(c[axis] + sign * (size[0] + c[1] * (1.0 + side * share)))
+                kinds.setdefault((share, side), []).append(v)
+    pts = [spread_pts] + [np.resize(np.asarray(v, np.float32), (256, 3)) for v in kinds.values()]
     _check(rm, oracle, renderer, spec, np.concatenate(pts).astype(np.float32))
 
 
