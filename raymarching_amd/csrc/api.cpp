@@ -772,6 +772,17 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
     sv.pa = ctx->d_pa.ptr; sv.pb = ctx->d_pb.ptr; sv.row_prim = ctx->d_row_prim.ptr;
     sv.colors = ctx->d_colors.ptr; sv.lights = ctx->d_lights.ptr;
     sv.n_lights = n_lights; sv.n_prims = ctx->program.n_prims;
+    {
+        double magnitude = 0.0;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            if (nodes[i].type == RM_LIST) continue;
+            const rm_node &n = nodes[i];
+            const double m = std::fabs((double)n.center[0]) + std::fabs((double)n.center[1]) + std::fabs((double)n.center[2]) +
+                             std::max(std::fabs((double)n.size[0]), std::max(std::fabs((double)n.size[1]), std::fabs((double)n.size[2])));
+            if (std::isfinite(m)) magnitude = std::max(magnitude, m);
+        }
+        sv.cap_slack = (float)(4e-6 * magnitude);
+    }
     sv.lattice = ctx->d_lattice.ptr;
     sv.lattice_words = ctx->program.n_lattices ? static_cast<uint32_t>(ctx->program.lattice.size()) : 0u;
     sv.camera = ctx->d_camera.ptr;

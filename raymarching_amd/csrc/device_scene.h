@@ -160,6 +160,9 @@ struct SceneView {
     // is uploaded (camera_sd_known = 0: not found, every ray evaluates it)
     float camera_sd;
     uint32_t camera_sd_known;
+    // 4e-6 of the largest |centre| + size among the scene's primitives: the part of the march loop's `cap` margin that
+    // covers the rounding of a value decided by a primitive far from the point or much larger than the step
+    float cap_slack;
 };
 
 constexpr uint32_t kTileBits = 27u, kTileMask = (1u << kTileBits) - 1u;

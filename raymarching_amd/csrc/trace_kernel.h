@@ -50,7 +50,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     // the maximum norm, which is smaller, and min, max and negation keep the property -- so after the
     // step p' = p + ray * sd, |p' - p| = |sd| (1 + 1e-7), the value at p' is at most sd + |sd|; 1e-5
     // relative and 4e-6 of the coordinates' magnitude cover the roundings of the step, of |ray| = 1 and
-    // of the evaluations on both sides (each below 1e-6 of the magnitudes involved).
+    // of the evaluations on both sides (each below 1e-6 of the magnitudes involved: the point's coordinates and, through
+    // SceneView::cap_slack, the centre and size of whichever primitive decides the value, however far or large).
     float cap[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) cap[s] = __builtin_inff();
@@ -77,7 +78,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
                 at[s] = p[s];
                 p[s] = p[s] + ray[s] * sd[s];
                 cap[s] = sd[s] + __builtin_fabsf(sd[s]) * 1.00001f +
-                         4e-6f * (__builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(sd[s]));
+                         4e-6f * (__builtin_fabsf(p[s].x) + __builtin_fabsf(p[s].y) + __builtin_fabsf(p[s].z) + __builtin_fabsf(sd[s])) + sc.cap_slack;
                 if (SHADOW) to_light[s] -= sd[s];
                 done[s] = sd[s] < fr.surface_eps || (SHADOW && to_light[s] < -past_light[s]);
                 if (COUNT) {

@@ -191,7 +191,7 @@ __device__ __forceinline__ void trace_refill_body(const SceneView &sc, const Fra
                 if (COUNT) cnt.steps++;
                 p = p + ray * sd[0];
                 cap = sd[0] + __builtin_fabsf(sd[0]) * 1.00001f +
-                      4e-6f * (__builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __builtin_fabsf(sd[0]));
+                      4e-6f * (__builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + __builtin_fabsf(sd[0])) + sc.cap_slack;
                 to_light -= sd[0];
                 steps++;
                 const bool ended = sd[0] < fr.surface_eps || to_light < -past_light || steps >= fr.iterations;

@@ -200,3 +200,35 @@ def test_frames_of_large_flat_scenes(rm, oracle, renderer, seed):
     gpu = renderer.render_f32()
     cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
     assert gpu.tobytes() == cpu.tobytes()
+
+
+def test_frame_of_a_flat_scene_on_a_huge_ground_sphere(rm, oracle, renderer):
+    """The upper bound the march loop hands the scene walker carries a margin for the rounding of the value it was
+    derived from; when that value is a primitive's whose centre lies thousands of units away (a ground sphere of
+    radius 5000), the margin has to grow with that primitive's magnitude, not only with the point's: a room, the
+    ground sphere and 300 loose primitives just above it, frame bit-identical to the oracle's."""
+    rng = np.random.default_rng(23)
+    lines = ["Bounds 400.0", "Camera Position 30.0 12.0 30.0", "Camera Direction -1.0 -0.35 -1.0", "Camera Up 0.0 1.0 0.0",
+             "Camera FOV 70", "Light 10.0 50.0 20.0", "Light -30.0 40.0 -10.0", "Color 0.4 0.5 0.3", "Sphere 0.0 -5000.0 0.0 5000.0"]
+    for _ in range(300):
+        t = ("Sphere", "Box", "Cross")[int(rng.integers(3))]
+        c = rng.uniform([-40, 0.2, -40], [40, 6, 40])
+        lines.append("Color %.3f %.3f %.3f" % tuple(rng.uniform(0, 1, 3)))
+        if t == "Sphere":
+            lines.append("Sphere %.4f %.4f %.4f %.4f" % (*c, rng.uniform(0.3, 2)))
+        elif t == "Box":
+            lines.append("Box %.4f %.4f %.4f %.4f %.4f %.4f" % (*c, *rng.uniform(0.3, 3, 3)))
+        else:
+            lines.append("Cross %.4f %.4f %.4f %.4f %.4f %.4f" % (*c, *rng.uniform(0.05, 0.4, 3)))
+    text = "\n".join(lines) + "\n"
+    kw = dict(width=72, height=48, kernel=2)
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(text=text))
+    gpu = renderer.render_f32()
+    cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
+    assert gpu.tobytes() == cpu.tobytes()
+    rng = np.random.default_rng(24)
+    pts = rng.uniform([-50, -0.5, -50], [50, 12, 50], (6000, 3)).astype(np.float32)
+    sd, _, sd_march = renderer.eval_sdf_both(pts)
+    osd, _ = oracle.Scene(text=text).sdf(pts)
+    assert sd.tobytes() == osd.tobytes() and sd_march.tobytes() == osd.tobytes()
