@@ -42,6 +42,34 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: starts one rank per GPU with torch.distributed.run as a CHILD
+    process -- before this process has imported torch or touched the GPU -- and hands on the child's output (rank 0's
+    one JSON line) and its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:               # a port that is free right now
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1 \
+        and "--rehearse-on-one-gpu" not in sys.argv:
+    sys.exit(_launch_ranks(_requested_gpus(sys.argv[1:])))
+
 # Frames in flight run on one HIP stream each; HIP maps streams onto this many hardware queues per process
 # (its default, 4, would let only four frames overlap).  Read when the runtime starts, hence set before torch.
 # A sharded run keeps up to 8 frames in flight (16 tried), and the collective's own stream must not share a queue
@@ -108,6 +136,21 @@ def cpu_baseline(scene_file, kw):
                 "sample": f"skipped: {sc.prim_count} primitives per SDF call are out of reach of the brute-force CPU path"}
     p = rmo.default_params(**kw)
     threads = rmo.max_threads()
+    if sc.prim_count * p.kernel * p.kernel <= 40:
+        # cheap enough for the whole frame on both legs, as the reference's main() times them (main.cpp:39-50)
+        t0 = time.perf_counter()
+        _, cnt = sc.render(p, threads=threads)
+        t_omp = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, cnt1 = sc.render(p, threads=1)
+        t_1 = time.perf_counter() - t0
+        return {
+            "value": round(cnt["rays"] / t_omp / 1e6, 5), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"render::OMP restatement, the whole {p.width}x{p.height} frame ({cnt['rays']} rays, {cnt['sdf_calls']} SDF calls) in {t_omp:.2f} s",
+            "frame_s": round(t_omp, 3),
+            "single_thread": {"value": round(cnt1["rays"] / t_1 / 1e6, 5), "unit": "Mrays/s", "cores": 1, "frame_s": round(t_1, 3),
+                              "sample": f"render::CPU restatement, the whole frame ({cnt1['rays']} rays) in {t_1:.2f} s"},
+        }
     step = max(1, p.height // 24)
     rows = (step // 2, p.height, step)                 # ~24 rows spread over the frame
     t0 = time.perf_counter()
@@ -154,7 +197,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit("--gpus N > 1 runs one process per GPU (python bench.py --gpus N starts them itself; "
+                         "--rehearse-on-one-gpu must be launched with torch.distributed.run --nproc-per-node N)")
+    if world > 1 and not a.rehearse_on_one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world}: this node shows {torch.cuda.device_count()} GPU(s); "
+                         "one rank per GPU is the only sharded mode (RCCL refuses two ranks on one device)")
     if a.rehearse_on_one_gpu:
         local = 0
         import faulthandler
@@ -542,6 +589,12 @@ def main():
             },
             "gathered_frame_equals_single_launch": gathered_ok,
             "frame_ms": round(ms_per_step, 4),
+            # the reference's definition of a frame (render::GPU, render.cpp:468-475: dispatch + read-back into the caller's
+            # host image), one frame at a time, page-locked image; and the rate of every ray marched -- beside `value`
+            "frame_alone_host_ms": host["frame_alone_ms_host"] if host else None,
+            "value_frame_alone_host": round(rays_per_frame / host["frame_alone_ms_host"] / 1e3, 3) if host else None,
+            "frame_alone_device_ms": host["frame_alone_ms"] if host else None,
+            "value_every_ray_marched": all_marched["value"] if all_marched else None,
             "host_issue_ms_per_frame": round(host_issue_ms, 4),
             "mrays_cast_per_s": round(total_rays * a.steps / elapsed / 1e6, 3),
             "every_ray_marched": all_marched,

@@ -323,9 +323,14 @@ int rm_set_lane_refill(rm_context *ctx, uint32_t tile_w_log2, uint32_t tile_h_lo
 int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int counting, char *buffer, size_t capacity,
                      size_t *length);
 int rm_kernel_source_compiles(const char *source);
-/* Process-wide: keeps compiled code objects in `directory` (an existing, writable directory) so that
- * later processes load them instead of compiling (0.3-1.3 s per scene).  NULL or "" turns it off (the
- * default).  A file is used only if the source and device headers stored in it equal the current ones. */
+/* Process-wide: where compiled code objects and measured tile orders are kept so that later processes load them
+ * instead of compiling (0.3-1.3 s per scene) or timing the tiles again.  ON BY DEFAULT: without this call the library
+ * uses $RM_KERNEL_CACHE_DIR, else $XDG_CACHE_HOME/raymarch_hip, $HOME/.cache/raymarch_hip, /tmp/raymarch_hip-<uid>
+ * (created 0700, used only if owned by the caller); NULL, "" here, or RM_KERNEL_CACHE_DIR=off in the environment,
+ * turn it off.  `directory` must exist and be writable.  A file is used only if the key stored in it (source and
+ * device headers; scene digest, parameters and launch shape for a tile order) equals the current one.  A tile order
+ * is written once a second frame of its configuration has used it, never by a configuration rendered once; the
+ * directory is kept below $RM_KERNEL_CACHE_MAX_MB (default 256) by deleting the files unused for longest. */
 int rm_set_kernel_cache_dir(const char *directory);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */

@@ -142,8 +142,10 @@ struct rm_context {
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
     DeviceArray<float> d_points, d_sd, d_camera;
+    DeviceArray<unsigned char> d_warm;   // target of the one-pixel launch that warms a freshly loaded kernel
     DeviceArray<uint32_t> d_prim, d_lattice, d_row_prim;
-    DeviceArray<uint32_t> d_grid_cells, d_grid_entries, d_grid_total;
+    DeviceArray<uint32_t> d_grid_cells, d_grid_entries;
+    DeviceArray<unsigned long long> d_grid_total;
     DeviceArray<float> d_grid_bound;
     double grid_build_ms = 0.0;
     uint64_t grid_entries = 0, grid_cells = 0;
@@ -167,6 +169,9 @@ struct rm_context {
     std::string scene_fingerprint;   // digest of the uploaded scene, camera and lights (keys cached tile orders)
     OrderKey order_key{};
     bool order_ready = false;
+    bool order_stored = false;       // the order in use is in the cache directory (or came from it)
+    std::vector<uint32_t> order_entries;   // the measured order, kept until it has been used again and stored
+    bool costs_valid = false;        // d_tile_cost holds the durations a render of this context measured (rm_get_tile_costs)
     uint32_t measured_tiles_x = 0, measured_tiles_y = 0;
     DeviceArray<uint32_t> d_band_list;
     std::vector<uint32_t> band_list_host;
@@ -351,6 +356,9 @@ bool load_tile_order(rm_context *ctx, const rm_context::OrderKey &key, size_t n_
     ctx->order_extra = (uint32_t)(entries.size() - n_tiles);
     ctx->order_key = key;
     ctx->order_ready = true;
+    ctx->order_stored = true;
+    ctx->order_entries.clear();
+    ctx->costs_valid = false;   // an order read from the cache comes without the durations behind it
     return true;
 }
 
@@ -423,6 +431,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         } else if (may_measure) {
             ctx->order_key = key;
             ctx->order_ready = false;
+            ctx->costs_valid = false;
             pend.measuring = true;
             ctx->measured_tiles_x = refill ? (sw + (1u << fr.refill_w_log2) - 1u) >> fr.refill_w_log2 : (sw + side * pts - 1u) / (side * pts);
             ctx->measured_tiles_y = refill ? (sh + (1u << fr.refill_h_log2) - 1u) >> fr.refill_h_log2 : (sh + side - 1u) / side;
@@ -517,7 +526,18 @@ int finish_bands(rm_context *ctx) {
         RM_HIP(hipStreamSynchronize(ctx->stream));
         ctx->order_extra = (uint32_t)(entries.size() - order.size());
         ctx->order_ready = true;
-        rmdev::store_cached_blob("tile-order:", order_cache_key(ctx, ctx->order_key, ctx->band_list_host), entries);
+        ctx->costs_valid = true;
+        // Kept in memory for now: the order goes to the cache directory once a later frame has used it (below), so that a
+        // caller who moves the camera or the scene every frame leaves no file per frame behind.
+        ctx->order_stored = false;
+        ctx->order_entries = std::move(entries);
+    } else if (pend.by_cost && !ctx->order_stored && !ctx->order_entries.empty()) {
+        // second frame of the configuration: worth keeping for later processes (the frame is finished; the write is
+        // the wait's, not the render's)
+        rmdev::store_cached_blob("tile-order:", order_cache_key(ctx, ctx->order_key, ctx->band_list_host), ctx->order_entries);
+        ctx->order_stored = true;
+        ctx->order_entries.clear();
+        ctx->order_entries.shrink_to_fit();
     }
     ctx->last = rm_counters{};
     ctx->last.tiles_by_cost = pend.by_cost ? 1u : 0u;
@@ -548,6 +568,12 @@ int finish_bands(rm_context *ctx) {
 int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8) {
     if (int rc = enqueue_bands(ctx, rows, d_f32, d_rgba8, true)) return rc;
     return finish_bands(ctx);
+}
+
+// most list entries a cell grid may hold; $RM_GRID_MAX_ENTRIES lowers it (tests of the fallback)
+unsigned long long grid_entry_limit() {
+    if (const char *env = std::getenv("RM_GRID_MAX_ENTRIES")) return std::strtoull(env, nullptr, 10);
+    return 1ull << 28;
 }
 
 // Builds the cell grid over the root's long runs (device_scene.h: GridView) on the device; leaves ctx->scene.grid empty
@@ -611,12 +637,13 @@ int build_grid(rm_context *ctx) {
     b.cells = ctx->d_grid_cells.ptr;
     b.bound = ctx->d_grid_bound.ptr;
     b.total = ctx->d_grid_total.ptr;
-    RM_HIP(hipMemsetAsync(b.total, 0, sizeof(uint32_t), ctx->stream));
+    RM_HIP(hipMemsetAsync(b.total, 0, sizeof(unsigned long long), ctx->stream));
     RM_HIP(rmdev::launch_count_grid(b, ctx->stream));
-    uint32_t total = 0;
+    unsigned long long total = 0;   // 64 bits: 2^24 cells of a thousand coincident rows each would wrap a 32-bit sum
     RM_HIP(hipMemcpyAsync(&total, b.total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
-    if ((uint64_t)total > (1ull << 28)) return RM_OK;   // a gigabyte of lists: leave such a scene to the hull walk
+    // a gigabyte of lists: leave such a scene to the hull walk (the cells' 32-bit offsets are only used below this)
+    if (total > grid_entry_limit()) return RM_OK;
     RM_HIP(ctx->d_grid_entries.reserve(total));
     b.entries = ctx->d_grid_entries.ptr;
     RM_HIP(rmdev::launch_fill_grid(b, ctx->stream));
@@ -683,6 +710,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->counting_module.unload();
     ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release(); ctx->h_tiles.release();
     ctx->d_grid_cells.release(); ctx->d_grid_entries.release(); ctx->d_grid_total.release(); ctx->d_grid_bound.release();
+    ctx->d_warm.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -707,6 +735,7 @@ int rm_reserve(rm_context *ctx) {
     if (!ctx->have_params) return fail(RM_ERR_STATE, "rm_set_params has not been called");
     RM_HIP(hipSetDevice(ctx->device));
     ctx->order_ready = false;   // the tile tables are cleared below: an order they held is read again, or measured again
+    ctx->costs_valid = false;
     const rm_params &p = ctx->params;
     const size_t pixels = (size_t)p.width * p.height;
     RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
@@ -851,11 +880,12 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         fr.iterations = 1;
         fr.surface_eps = fr.offset_eps = 1e-3f;
         fr.band_rows = fr.band_stride = fr.band_count = 1u;
-        if (void *spare = static_scratch(ctx->device)) {
-            RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, static_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
-            RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, static_cast<rmdev::Sample *>(spare), nullptr, static_cast<unsigned char *>(spare) + 256, ctx->stream));
-            RM_HIP(hipStreamSynchronize(ctx->stream));
-        }
+        // into a buffer of the context's own: the GPU's static scratch may hold another context's frame in flight
+        RM_HIP(ctx->d_warm.reserve(512));
+        unsigned char *const spare = ctx->d_warm.ptr;
+        RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
+        RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return preload_tile_order(ctx);
 }
@@ -1047,6 +1077,7 @@ int rm_set_tile_scheduling(rm_context *ctx, int mode) {
     if (mode != RM_TILES_NATURAL && mode != RM_TILES_BY_COST) return fail(RM_ERR_INVALID, "rm_set_tile_scheduling: unknown mode");
     ctx->tile_scheduling = mode;
     ctx->order_ready = false;
+    ctx->costs_valid = false;
     return RM_OK;
 }
 
@@ -1083,7 +1114,9 @@ int rm_set_band_list(rm_context *ctx, const uint32_t *image_bands, uint32_t coun
 
 int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_t *tiles_x, uint32_t *tiles_y) {
     if (!ctx || !tiles_x || !tiles_y) return fail(RM_ERR_INVALID, "rm_get_tile_costs: null argument");
-    if (!ctx->order_ready) return fail(RM_ERR_STATE, "rm_get_tile_costs: no render has timed its tiles yet");
+    if (!ctx->costs_valid)
+        return fail(RM_ERR_STATE, "rm_get_tile_costs: no render of this context has timed the tiles of its current configuration "
+                                  "(an order read from the cache directory comes without durations)");
     *tiles_x = ctx->measured_tiles_x;
     *tiles_y = ctx->measured_tiles_y;
     const size_t n = (size_t)ctx->measured_tiles_x * ctx->measured_tiles_y;

@@ -6,14 +6,18 @@
 
 #include <hip/hiprtc.h>
 
+#include <dirent.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <cerrno>
 #include <cstdlib>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -111,11 +115,43 @@ std::string cache_file(const std::string &dir, const std::string &key) {
     return dir + name;
 }
 
+// A file that was just read counts as used now: eviction goes by modification time.
+void mark_used(const std::string &path) { (void)utimes(path.c_str(), nullptr); }
+
+// Keeps the directory's rm_*.gfx950.bin files below $RM_KERNEL_CACHE_MAX_MB (default 256): after a store, the files
+// unused for longest go until three quarters of the limit are left.  Only files this library names are touched.
+void evict_old_files(const std::string &dir) {
+    unsigned long long limit = 256ull << 20;
+    if (const char *env = std::getenv("RM_KERNEL_CACHE_MAX_MB")) limit = std::strtoull(env, nullptr, 10) << 20;
+    DIR *d = opendir(dir.c_str());
+    if (!d) return;
+    struct Entry { std::string path; unsigned long long bytes; long long used; };
+    std::vector<Entry> files;
+    unsigned long long total = 0;
+    while (const dirent *e = readdir(d)) {
+        const size_t n = std::strlen(e->d_name);
+        if (n < 15 || std::strncmp(e->d_name, "rm_", 3) != 0 || std::strcmp(e->d_name + n - 11, ".gfx950.bin") != 0) continue;
+        const std::string path = dir + "/" + e->d_name;
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+        files.push_back({ path, (unsigned long long)st.st_size, (long long)st.st_mtime });
+        total += (unsigned long long)st.st_size;
+    }
+    closedir(d);
+    if (total <= limit) return;
+    std::sort(files.begin(), files.end(), [](const Entry &a, const Entry &b) { return a.used < b.used; });
+    for (const Entry &f : files) {
+        if (total <= limit / 4u * 3u) break;
+        if (std::remove(f.path.c_str()) == 0) total -= f.bytes;
+    }
+}
+
 CodeObject load_from_disk(const std::string &source) {
     const std::string dir = cache_dir();
     if (dir.empty()) return nullptr;
     const std::string key = cache_key_text(source);
-    std::FILE *f = std::fopen(cache_file(dir, key).c_str(), "rb");
+    const std::string path = cache_file(dir, key);
+    std::FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return nullptr;
     unsigned long long key_size = 0, code_size = 0;
     CodeObject result;
@@ -128,6 +164,7 @@ CodeObject load_from_disk(const std::string &source) {
             result = code;
     }
     std::fclose(f);
+    if (result) mark_used(path);
     return result;
 }
 
@@ -143,6 +180,7 @@ void store_to_disk(const std::string &source, const std::vector<char> &code) {
     std::fclose(f);
     if (ok) std::rename(tmp.c_str(), path.c_str());   // atomic: readers see a whole file or none
     else std::remove(tmp.c_str());
+    if (ok) evict_old_files(dir);
 }
 
 CodeObject build_code_object(const std::string &source, std::string &log) {
@@ -195,7 +233,8 @@ void SceneModule::unload() {
 bool load_cached_blob(const std::string &kind, const std::string &key, std::vector<uint32_t> &words) {
     const std::string dir = cache_dir();
     if (dir.empty()) return false;
-    std::FILE *f = std::fopen(cache_file(dir, kind + key).c_str(), "rb");
+    const std::string path = cache_file(dir, kind + key);
+    std::FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     unsigned long long key_size = 0, n_words = 0;
     bool ok = std::fread(&key_size, sizeof key_size, 1, f) == 1 && std::fread(&n_words, sizeof n_words, 1, f) == 1 &&
@@ -207,6 +246,7 @@ bool load_cached_blob(const std::string &kind, const std::string &key, std::vect
              (n_words == 0 || std::fread(words.data(), sizeof(uint32_t), n_words, f) == n_words);
     }
     std::fclose(f);
+    if (ok) mark_used(path);
     return ok;
 }
 
@@ -223,6 +263,7 @@ void store_cached_blob(const std::string &kind, const std::string &key, const st
     std::fclose(f);
     if (ok) std::rename(tmp.c_str(), path.c_str());
     else std::remove(tmp.c_str());
+    if (ok) evict_old_files(dir);
 }
 
 void set_kernel_cache_dir(const char *dir) {

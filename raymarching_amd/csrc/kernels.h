@@ -38,7 +38,7 @@ struct GridBuild {
     uint32_t dims[3];
     uint32_t *cells;
     float *bound;                 // H per cell
-    uint32_t *total;
+    unsigned long long *total;   // 64 bits: per-cell list sizes of heavily overlapping rows can sum beyond 2^32
     uint32_t *entries;            // fill pass
 };
 hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream);

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
             }
         }
     if (!FILL) {
-        b.cells[4u * cell] = atomicAdd(b.total, n[0] + n[1] + n[2]);
+        // the host uses the grid only if the 64-bit total stays below 2^28, so the 32 bits kept here are the whole offset then
+        b.cells[4u * cell] = (uint32_t)atomicAdd(b.total, (unsigned long long)(n[0] + n[1] + n[2]));
         b.cells[4u * cell + 1u] = n[0];
         b.cells[4u * cell + 2u] = n[1];
         b.cells[4u * cell + 3u] = n[2];

@@ -16,6 +16,8 @@ rm_params params = { 1024u, 768u, 3u, 1000, 0.05f, 1e-3f, 1e-3f };
 
 namespace render {
 
+void unpin(void);
+
 namespace {
 
 rm_context *g_ctx = nullptr;
@@ -23,17 +25,18 @@ bool g_ok = true;
 std::string g_error;
 // The caller's image buffer, page-locked the first time GPU() sees it so that the read-back is a copy-engine
 // transfer instead of a staged one (the reference's caller allocates the buffer once and reuses it, main.cpp:56).
+// The registration is on the caller's memory: the image must stay allocated until render::destroy() or render::unpin()
+// (a buffer freed and allocated again at the same address would otherwise be taken for the locked one).
 void *g_pinned = nullptr;
-
-void unpin() {
-    if (g_pinned) (void)rm_host_unregister(g_pinned);
-    g_pinned = nullptr;
-}
+size_t g_pinned_bytes = 0;
 
 void pin(void *image, size_t bytes) {
-    if (image == g_pinned) return;
+    if (image == g_pinned && bytes <= g_pinned_bytes) return;   // the same buffer asked for more (float after 8-bit frames) is locked anew
     unpin();
-    if (rm_host_register(image, bytes) == RM_OK) g_pinned = image;   // a buffer that cannot be locked still works, more slowly
+    if (rm_host_register(image, bytes) == RM_OK) {   // a buffer that cannot be locked still works, more slowly
+        g_pinned = image;
+        g_pinned_bytes = bytes;
+    }
 }
 
 void report(int rc, const char *what) {
@@ -53,6 +56,12 @@ bool have_context(const char *what) {
 }
 
 }  // namespace
+
+void unpin(void) {
+    if (g_pinned) (void)rm_host_unregister(g_pinned);
+    g_pinned = nullptr;
+    g_pinned_bytes = 0;
+}
 
 void setup::context(void) {
     if (g_ctx) {

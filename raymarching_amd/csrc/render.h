@@ -25,6 +25,8 @@ extern rm_params params;
 
 namespace render {
 
+// GPU() page-locks the caller's image the first time it sees it (hipHostRegister) and keeps that registration: the image
+// must stay allocated until destroy() or unpin().  Free or reallocate it only after one of the two.
 void GPU(unsigned char *image);
 
 namespace setup {
@@ -41,5 +43,6 @@ void GPU(float *image);      // float RGBA frame, as the CPU operators' Image2D<
 bool ok(void);               // did the last operator succeed
 const char *error(void);     // message of the last failure
 rm_context *context(void);   // the underlying C-ABI context (null before setup::context)
+void unpin(void);            // drops the page-lock GPU() holds on the caller's image (before the caller frees it)
 
 }  // namespace render

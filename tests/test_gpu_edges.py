@@ -136,3 +136,36 @@ def test_deepest_nesting_and_one_level_more(rm, oracle, renderer):
     with pytest.raises(rm.RaymarchError, match="nested deeper"):
         renderer.set_scene_raw(_nested(rm.Node, 10), np.zeros((0, 3), np.float32), ident, 1.0)
     renderer.set_scene_raw(ok, np.zeros((0, 3), np.float32), ident, 1.0)   # the context is still usable
+
+
+@pytest.mark.parametrize("lights", [1, 2])
+def test_coloured_sample_with_a_nan_normal(rm, oracle, renderer, lights):
+    """normalize(grad) of a zero gradient is NaN (scene.cpp:28) and the lighting clamp then decides the sample
+    (scene.cpp:60).  The camera sits at the centre of a coloured cube so small that the first step (applied before the
+    test, scene.cpp:37-39) does not move the position: every ray ends where it began, all six gradient taps give the
+    same value, the normal is NaN, every shadow ray starts at NaN and runs its full iteration count, and the sample is
+    saturation x colour -- with the reference's min(max(saturation, NaN), 1).  Both shading modes, both kernel modes."""
+    f3 = C.c_float * 3
+
+    def nodes(node):
+        return [node(LIST, 0, 3, f3(0, 0, 0), f3(0, 0, 0), f3(0, 0, 0)),
+                node(LIST, 1, 1, f3(0, 0, 0), f3(0, 0, 0), f3(0, 0, 0)),            # Bounds: COMPLEMENT { box }
+                node(BOX, 0, 0, f3(0, 0, 0), f3(200, 200, 200), f3(0, 0, 0)),
+                node(BOX, 0, 0, f3(0, 0, 0), f3(2e-30, 2e-30, 2e-30), f3(1.0, 0.5, 0.25)),
+                node(SPHERE, 0, 0, f3(0, -30, -40), f3(10, 0, 0), f3(0, 1, 0))]
+    light_xyz = np.array([[30, 40, 10], [-20, 50, -30]], np.float32)[:lights]
+    for iterations in (1, 25):
+        kw = dict(width=24, height=10, kernel=2, iterations=iterations)
+        # camera at the origin (the cube's centre), looking down -z
+        orc = oracle.Scene(nodes=nodes(oracle.Node), lights=light_xyz, cam_position=(0, 0, 0), cam_direction=(0, 0, -1), cam_fov=70.0)
+        transform, focal = orc.camera()
+        cpu, _ = orc.render(oracle.default_params(**kw))
+        assert np.allclose(cpu[..., :3], np.float32(0.05) * np.array([1.0, 0.5, 0.25], np.float32)), "the oracle's samples are saturation x colour"
+        renderer.set_params(rm.default_params(**kw))
+        renderer.set_scene_raw(nodes(rm.Node), light_xyz, transform, float(focal))
+        try:
+            for coloured_only in (True, False):
+                renderer.set_shading(coloured_only)
+                assert renderer.render_f32().tobytes() == cpu.tobytes(), f"iterations={iterations} coloured_only={coloured_only}"
+        finally:
+            renderer.set_shading(True)

@@ -51,3 +51,30 @@ def test_code_objects_are_kept_on_disk_when_asked(rm, tmp_path):
         assert len(list(tmp_path.iterdir())) == 2
     finally:
         rm.set_kernel_cache_dir(None)
+
+
+def test_cache_directory_stays_below_its_limit(rm, tmp_path, monkeypatch):
+    """The files unused for longest go once the directory outgrows $RM_KERNEL_CACHE_MAX_MB."""
+    import os
+    import time
+    base = rm.kernel_source(rm.Scene(scene_path("menger2.txt")))
+    rm.set_kernel_cache_dir(str(tmp_path))
+    try:
+        rm.kernel_source_compiles(base)
+        one = sum(f.stat().st_size for f in tmp_path.iterdir())
+        assert one > 10000
+        monkeypatch.setenv("RM_KERNEL_CACHE_MAX_MB", "1")
+        n = (1 << 20) // one + 3                       # enough sources to outgrow one megabyte
+        names = []
+        for i in range(n):
+            rm.kernel_source_compiles(base.replace("rm_eval_sdf", f"rm_eval_sdf_{i}"))
+            newest = max(tmp_path.iterdir(), key=lambda f: f.stat().st_mtime_ns)
+            names.append(newest.name)
+            old = time.time() - 1000 + i               # distinct, rising times of last use
+            os.utime(newest, (old, old))
+        left = {f.name for f in tmp_path.iterdir()}
+        assert sum(f.stat().st_size for f in tmp_path.iterdir()) <= (1 << 20)
+        assert len(left) < n + 1 and names[-1] in left   # the newest survives, some older ones are gone
+        assert all(name.startswith("rm_") and name.endswith(".gfx950.bin") for name in left)
+    finally:
+        rm.set_kernel_cache_dir(None)
