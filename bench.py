@@ -237,6 +237,9 @@ def main():
     G = a.frames_per_gather if a.frames_per_gather > 0 else (1 if split < 8 else 2)
     if F % G:
         raise SystemExit("--frames-in-flight must be a multiple of --frames-per-gather")
+    if a.balance:
+        # dealing by cost needs the tiles' measured durations; a tile order read from the cache directory comes without them
+        rm.set_kernel_cache_dir(None)
     rs, set_scene_s = [], 0.0
     for f in range(F):
         rr = rm.Renderer(local)

@@ -362,6 +362,44 @@ int rm_scene_camera(const rm_scene *scene, float transform[16], float *focal);
 /* rm_set_scene from a loaded scene. */
 int rm_set_scene_from(rm_context *ctx, const rm_scene *scene);
 
+/* ---- one frame over several GPUs of a node, one process ---------------------------------------------------
+ *
+ * The reference's render::GPU (render.cpp:468-475) drives one device.  An rm_multi owns one rendering context
+ * per entry of `devices` (its ranks), deals the frame's row bands to them cyclically (band b of RM_MULTI_BAND_ROWS
+ * rows belongs to rank b mod n; every pixel is independent, render.cpp:122-129), has every rank render its share
+ * into its own device memory, and gathers the shares into one frame on rank 0's device -- the one exchange step of
+ * the path -- from where the frame goes to the caller.  The gathered frame equals the frame one context renders,
+ * bit for bit.
+ *   transport  RM_MULTI_RCCL   grouped ncclSend / ncclRecv of every rank's share to rank 0 over xGMI (librccl is
+ *                              loaded when the first such object is created; one communicator per rank from
+ *                              ncclCommInitAll), then a de-interleaving copy on rank 0's device;
+ *              RM_MULTI_COPY   peer copies (hipMemcpy2DAsync between the devices' memories), which also serve a
+ *                              device list that names a GPU more than once -- RCCL refuses two ranks on one
+ *                              device -- so that the whole path can be exercised on a single GPU;
+ *              RM_MULTI_AUTO   RCCL when n > 1 and all devices differ, copies otherwise.
+ * Calls on one rm_multi are serialised by the caller, like calls on a context.  The first frame of a configuration
+ * renders rank after rank (each times its tiles); later frames run on all ranks at once.
+ */
+typedef struct rm_multi rm_multi;
+typedef enum rm_multi_transport { RM_MULTI_AUTO = 0, RM_MULTI_RCCL = 1, RM_MULTI_COPY = 2 } rm_multi_transport;
+#define RM_MULTI_BAND_ROWS 4u
+int rm_multi_create(const int *devices, uint32_t n_devices, int transport, rm_multi **out);
+int rm_multi_destroy(rm_multi *m);
+/* rm_set_params / rm_set_scene / rm_set_scene_from on every rank (render::push, render.cpp:447-466). */
+int rm_multi_set_params(rm_multi *m, const rm_params *params);
+int rm_multi_set_scene(rm_multi *m, const rm_node *nodes, uint32_t n_nodes, const float *lights_xyz, uint32_t n_lights,
+                       const float transform[16], float focal);
+int rm_multi_set_scene_from(rm_multi *m, const rm_scene *scene);
+/* render::GPU (render.cpp:468-475) on all ranks: the whole frame, RGBA8, into the caller's host image
+ * (width * height * 4 bytes, row 0 = top), or into device memory on rank 0's device. */
+int rm_multi_render_rgba8(rm_multi *m, uint8_t *host_image);
+int rm_multi_render_device(rm_multi *m, uint8_t *device_rgba8);
+/* Rank r's context (settings such as rm_set_kernel_mode or rm_set_shading before the scene is set, counters after a
+ * frame), the number of ranks, and the transport in use (RM_MULTI_RCCL or RM_MULTI_COPY). */
+rm_context *rm_multi_context(rm_multi *m, uint32_t rank);
+uint32_t rm_multi_ranks(const rm_multi *m);
+int rm_multi_transport_in_use(const rm_multi *m);
+
 /* Writes an RGBA8 image as a PNG file (stored/deflate-less zlib stream). */
 int rm_write_png(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);
 

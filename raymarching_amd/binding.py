@@ -13,6 +13,8 @@ EXPORTS = (
     "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
+    "rm_multi_create", "rm_multi_destroy", "rm_multi_set_params", "rm_multi_set_scene", "rm_multi_set_scene_from",
+    "rm_multi_render_rgba8", "rm_multi_render_device", "rm_multi_context", "rm_multi_ranks", "rm_multi_transport_in_use",
 )
 
 
@@ -119,6 +121,18 @@ def lib():
     L.rm_scene_camera.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.rm_set_scene_from.argtypes = [vp, vp]
     L.rm_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.rm_multi_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.rm_multi_destroy.argtypes = [vp]
+    L.rm_multi_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.rm_multi_set_scene.argtypes = [vp, C.POINTER(Node), C.c_uint32, vp, C.c_uint32, vp, C.c_float]
+    L.rm_multi_set_scene_from.argtypes = [vp, vp]
+    L.rm_multi_render_rgba8.argtypes = [vp, vp]
+    L.rm_multi_render_device.argtypes = [vp, vp]
+    L.rm_multi_context.argtypes = [vp, C.c_uint32]
+    L.rm_multi_context.restype = vp
+    L.rm_multi_ranks.argtypes = [vp]
+    L.rm_multi_ranks.restype = C.c_uint32
+    L.rm_multi_transport_in_use.argtypes = [vp]
     _lib = L
     return L
 
@@ -334,6 +348,73 @@ class Renderer:
     @property
     def stream(self):
         return lib().rm_stream(self._h)
+
+
+class _BorrowedRenderer(Renderer):
+    """A rank's context of a MultiRenderer: settings and counters; the MultiRenderer owns it."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        self.params = None
+
+    def close(self):
+        self._h = None
+
+
+MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
+
+
+class MultiRenderer:
+    """Owning wrapper of an rm_multi: one frame over the listed devices (a device may be listed more than once)."""
+
+    def __init__(self, devices, transport=MULTI_AUTO):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().rm_multi_create(arr, len(devices), transport, C.byref(self._h)), "rm_multi_create")
+        self.params = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rm_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if lib is not None and _lib is not None:
+            self.close()
+
+    @property
+    def ranks(self):
+        return lib().rm_multi_ranks(self._h)
+
+    @property
+    def transport(self):
+        return lib().rm_multi_transport_in_use(self._h)
+
+    def context(self, rank):
+        h = lib().rm_multi_context(self._h, rank)
+        if not h:
+            raise RaymarchError(f"rm_multi_context: no rank {rank}")
+        return _BorrowedRenderer(h)
+
+    def set_params(self, params):
+        _check(lib().rm_multi_set_params(self._h, C.byref(params)), "rm_multi_set_params")
+        self.params = params
+
+    def set_scene(self, scene):
+        _check(lib().rm_multi_set_scene_from(self._h, scene.handle), "rm_multi_set_scene_from")
+
+    def render_rgba8(self, out=None):
+        """The frame in host memory: a new numpy array, or the page-locked / ordinary buffer at address `out`."""
+        p = self.params
+        if out is not None:
+            _check(lib().rm_multi_render_rgba8(self._h, out), "rm_multi_render_rgba8")
+            return None
+        img = np.zeros((p.height, p.width, 4), np.uint8)
+        _check(lib().rm_multi_render_rgba8(self._h, img.ctypes.data), "rm_multi_render_rgba8")
+        return img
+
+    def render_device(self, rgba8_ptr):
+        _check(lib().rm_multi_render_device(self._h, rgba8_ptr), "rm_multi_render_device")
 
 
 class HostBuffer:

@@ -39,6 +39,13 @@ int fail(rm_status code, const std::string &what) {
     return code;
 }
 
+}  // namespace
+
+// for the library's other files (multi.cpp): the calling thread's rm_last_error()
+int rm_internal_fail(int code, const std::string &what) { return fail(static_cast<rm_status>(code), what); }
+
+namespace {
+
 #define RM_HIP(expr)                                                                            \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \

@@ -5,7 +5,7 @@
 //
 //   raymarch [--scene scene/objects.txt] [--width 1024] [--height 768] [--ssaa 3] [--iterations 1000]
 //            [--frames 1] [--out out_gpu.png] [--raw out_gpu.rgba] [--exhaustive] [--interpreted]
-//            [--kernel-cache DIR] [--shade-all]
+//            [--kernel-cache DIR] [--shade-all] [--gpus N | --devices 0,1,...]
 //
 // The CPU renders of the reference's main() (render::CPU / render::OMP) are not part of this
 // library; their lines are printed as "not built" so that the report keeps its shape.
@@ -29,7 +29,8 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 int usage(const char *argv0) {
     std::cout << "usage: " << argv0
               << " [--scene PATH] [--width W] [--height H] [--ssaa K] [--iterations N] [--frames N]\n"
-                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted] [--kernel-cache DIR] [--shade-all]\n";
+                 "       [--out FILE.png] [--raw FILE.rgba] [--exhaustive] [--interpreted] [--kernel-cache DIR] [--shade-all]\n"
+                 "       [--gpus N | --devices 0,1,...]   (the frame sharded over several GPUs; a device may be named twice)\n";
     return 2;
 }
 
@@ -39,6 +40,7 @@ int main(int argc, char **argv) {
     std::string scene_path = "scene/objects.txt", out_png = "out_gpu.png", out_raw;
     int frames = 1;
     bool exhaustive = false, interpreted = false, shade_all = false;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -53,6 +55,8 @@ int main(int argc, char **argv) {
         else if (a == "--ssaa") constants::params.kernel = (uint32_t)std::atoi(v);
         else if (a == "--iterations") constants::params.iterations = std::atoi(v);
         else if (a == "--frames") frames = std::atoi(v);
+        else if (a == "--gpus") { devices.clear(); for (int d = 0; d < std::atoi(v); d++) devices.push_back(d); }
+        else if (a == "--devices") { devices.clear(); for (const char *c = v; *c;) { devices.push_back((int)std::strtol(c, const_cast<char **>(&c), 10)); if (*c == ',') c++; else if (*c) return usage(argv[0]); } }
         else if (a == "--out") out_png = v;
         else if (a == "--raw") out_raw = v;
         else if (a == "--kernel-cache") rm_set_kernel_cache_dir(v);
@@ -65,11 +69,16 @@ int main(int argc, char **argv) {
     scene::load(scene_path.c_str());
 
     std::cout << "...Setting up context" << std::endl;
+    if (!devices.empty()) render::setup::devices(devices.data(), (unsigned)devices.size());
     render::setup::context();
     if (!render::ok()) return 1;
-    if (exhaustive) rm_set_evaluator(render::context(), RM_EVAL_EXHAUSTIVE);
-    if (interpreted) rm_set_kernel_mode(render::context(), RM_KERNEL_INTERPRETED);
-    if (shade_all) rm_set_shading(render::context(), RM_SHADE_ALL);
+    const uint32_t n_ranks = render::multi() ? rm_multi_ranks(render::multi()) : 1u;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        rm_context *ctx = render::multi() ? rm_multi_context(render::multi(), r) : render::context();
+        if (exhaustive) rm_set_evaluator(ctx, RM_EVAL_EXHAUSTIVE);
+        if (interpreted) rm_set_kernel_mode(ctx, RM_KERNEL_INTERPRETED);
+        if (shade_all) rm_set_shading(ctx, RM_SHADE_ALL);
+    }
 
     std::cout << "...Compiling shaders" << std::endl;
     auto t0 = std::chrono::steady_clock::now();
@@ -113,6 +122,9 @@ int main(int argc, char **argv) {
     std::cout << "Render + Copy on GPU:\t\t" << first_s + push_s << "s" << std::endl;
     if (frames > 1) std::cout << "Render with GPU (later frames):\t" << render_s << "s per frame over " << frames - 1 << std::endl;
     std::cout << "Kernel compile:\t\t\t" << compile_s << "s" << std::endl;
+    if (render::multi())
+        std::cout << "Devices:\t\t\t" << n_ranks << " ranks, shares gathered by "
+                  << (rm_multi_transport_in_use(render::multi()) == RM_MULTI_RCCL ? "RCCL send/recv" : "peer copies") << std::endl;
     std::cout << "Trace kernel:\t\t\t" << c.kernel_ms * 1e-3 << "s (" << (c.compiled_kernel ? "compiled for the scene" : "record walker")
               << "), resolve " << c.resolve_ms * 1e-3 << "s" << std::endl;
     std::cout << "Throughput:\t\t\t" << rays / render_s / 1e6 << " Mrays/s (" << (uint64_t)rays << " rays per frame, " << frames

@@ -9,6 +9,7 @@
 
 #include <iostream>
 #include <string>
+#include <vector>
 
 namespace constants {
 rm_params params = { 1024u, 768u, 3u, 1000, 0.05f, 1e-3f, 1e-3f };
@@ -20,7 +21,9 @@ void unpin(void);
 
 namespace {
 
-rm_context *g_ctx = nullptr;
+rm_context *g_ctx = nullptr;     // one device (the reference's case), or rank 0's context of g_multi
+rm_multi *g_multi = nullptr;     // setup::devices() named more than one rank: the frame is sharded over them
+std::vector<int> g_devices = { 0 };
 bool g_ok = true;
 std::string g_error;
 // The caller's image buffer, page-locked the first time GPU() sees it so that the read-back is a copy-engine
@@ -63,12 +66,19 @@ void unpin(void) {
     g_pinned_bytes = 0;
 }
 
+void setup::devices(const int *device_ids, unsigned count) {
+    g_devices.assign(device_ids, device_ids + (device_ids ? count : 0u));
+    if (g_devices.empty()) g_devices.push_back(0);
+}
+
 void setup::context(void) {
-    if (g_ctx) {
-        rm_destroy(g_ctx);
-        g_ctx = nullptr;
-    }
-    report(rm_create(0, &g_ctx), "Failed to create HIP context");
+    if (g_multi) rm_multi_destroy(g_multi);
+    else if (g_ctx) rm_destroy(g_ctx);
+    g_multi = nullptr;
+    g_ctx = nullptr;
+    if (g_devices.size() == 1) return report(rm_create(g_devices[0], &g_ctx), "Failed to create HIP context");
+    report(rm_multi_create(g_devices.data(), (uint32_t)g_devices.size(), RM_MULTI_AUTO, &g_multi), "Failed to create HIP contexts");
+    if (g_multi) g_ctx = rm_multi_context(g_multi, 0);
 }
 
 // Where the reference compiles and links shader.comp (render.cpp:428-437): generates and
@@ -84,38 +94,48 @@ void setup::shaders(void) {
 // Where the reference creates its texture and SSBOs (render.cpp:439-445): sizes the device buffers of a frame.
 void setup::buffers(void) {
     if (!have_context("setup::buffers")) return;
-    int rc = rm_set_params(g_ctx, &constants::params);
-    if (rc == RM_OK) rc = rm_reserve(g_ctx);
+    int rc = g_multi ? rm_multi_set_params(g_multi, &constants::params) : rm_set_params(g_ctx, &constants::params);
+    if (rc == RM_OK && !g_multi) rc = rm_reserve(g_ctx);   // the ranks of a sharded frame size their shares at the first frame
     report(rc, "Failed to allocate buffers");
 }
 
 void push(void) {
     if (!have_context("push")) return;
-    int rc = rm_set_params(g_ctx, &constants::params);
+    int rc = g_multi ? rm_multi_set_params(g_multi, &constants::params) : rm_set_params(g_ctx, &constants::params);
     if (rc != RM_OK) return report(rc, "Failed to upload constants");
     const scene::Scene &sc = scene::current();
     const std::vector<rm_node> nodes = sc.nodes();
     const std::vector<float> lights = sc.light_positions();
-    rc = rm_set_scene(g_ctx, nodes.data(), static_cast<uint32_t>(nodes.size()), lights.data(),
-                      static_cast<uint32_t>(lights.size() / 3), sc.camera->transform.m, sc.camera->focal);
+    rc = g_multi ? rm_multi_set_scene(g_multi, nodes.data(), static_cast<uint32_t>(nodes.size()), lights.data(),
+                                      static_cast<uint32_t>(lights.size() / 3), sc.camera->transform.m, sc.camera->focal)
+                 : rm_set_scene(g_ctx, nodes.data(), static_cast<uint32_t>(nodes.size()), lights.data(),
+                                static_cast<uint32_t>(lights.size() / 3), sc.camera->transform.m, sc.camera->focal);
     report(rc, "Failed to upload scene");
 }
 
 void GPU(unsigned char *image) {
     if (!have_context("GPU")) return;
     if (image) pin(image, (size_t)constants::params.width * constants::params.height * 4);
-    report(rm_render_rgba8(g_ctx, image), "Failed to render");
+    report(g_multi ? rm_multi_render_rgba8(g_multi, image) : rm_render_rgba8(g_ctx, image), "Failed to render");
 }
 
 void GPU(float *image) {
     if (!have_context("GPU")) return;
+    if (g_multi) {
+        g_ok = false;
+        g_error = "GPU(float*): a frame sharded over several devices is gathered as RGBA8 only";
+        std::cout << "[Error] " << g_error << std::endl;
+        return;
+    }
     if (image) pin(image, (size_t)constants::params.width * constants::params.height * 4 * sizeof(float));
     report(rm_render_f32(g_ctx, image), "Failed to render");
 }
 
 void destroy(void) {
     unpin();
-    if (g_ctx) rm_destroy(g_ctx);
+    if (g_multi) rm_multi_destroy(g_multi);
+    else if (g_ctx) rm_destroy(g_ctx);
+    g_multi = nullptr;
     g_ctx = nullptr;
     g_ok = true;
 }
@@ -123,5 +143,6 @@ void destroy(void) {
 bool ok(void) { return g_ok; }
 const char *error(void) { return g_error.c_str(); }
 rm_context *context(void) { return g_ctx; }
+rm_multi *multi(void) { return g_multi; }
 
 }  // namespace render

@@ -30,6 +30,10 @@ namespace render {
 void GPU(unsigned char *image);
 
 namespace setup {
+// Extension: the devices the frame is rendered on, before context().  One device (the default: device 0) is the
+// reference's case; with more, context() creates one rank per entry and GPU() shards every frame over them by row
+// bands and gathers it (rm_multi_*: RCCL between distinct devices).
+void devices(const int *device_ids, unsigned count);
 void context(void);
 void shaders(void);
 void buffers(void);
@@ -42,7 +46,8 @@ void destroy(void);
 void GPU(float *image);      // float RGBA frame, as the CPU operators' Image2D<float4>
 bool ok(void);               // did the last operator succeed
 const char *error(void);     // message of the last failure
-rm_context *context(void);   // the underlying C-ABI context (null before setup::context)
+rm_context *context(void);   // the underlying C-ABI context (null before setup::context); rank 0's of a sharded set-up
+rm_multi *multi(void);       // the sharded set-up's object (null with one device)
 void unpin(void);            // drops the page-lock GPU() holds on the caller's image (before the caller frees it)
 
 }  // namespace render

@@ -1,0 +1,82 @@
+"""rm_multi_*: one frame over several ranks from one process (the native counterpart of bench.py's one-process-per-GPU
+sharding).  A GPU box has one GPU, so the device list names it several times and the shares are gathered by copies;
+the gathered frame must be the frame one context renders (every pixel is independent: render::CPU's loops,
+/root/reference/source/render.cpp:122-129), whatever the number of ranks and however the image's height cuts the bands."""
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(rm, scene, params):
+    r = rm.Renderer(0)
+    try:
+        r.set_params(params)
+        r.set_scene(scene)
+        return r.render_rgba8()
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("ranks,kw", [(3, dict(width=200, height=150, kernel=3)), (1, dict(width=64, height=33, kernel=2)),
+                                      (5, dict(width=97, height=77, kernel=2)), (8, dict(width=64, height=20, kernel=1)),
+                                      (4, dict(width=33, height=3, kernel=4))])
+def test_frame_gathered_from_ranks_on_one_gpu_equals_single_launch(rm, oracle, ranks, kw):
+    scene = rm.Scene(scene_path("default.txt"))
+    p = rm.default_params(**kw)
+    want = _single(rm, scene, p)
+    m = rm.MultiRenderer([0] * ranks)
+    try:
+        assert m.ranks == ranks and m.transport == rm.MULTI_COPY
+        m.set_params(p)
+        m.set_scene(scene)
+        for i in range(3):                       # rank after rank with the tiles timed, then all ranks at once in cost order
+            got = m.render_rgba8()
+            assert got.tobytes() == want.tobytes(), f"frame {i}"
+        if ranks == 3:
+            c = m.context(1).counters()
+            assert c["tiles_by_cost"] == 1 and c["compiled_kernel"] == 1
+            # another frame size on the same object: buffers and plan follow
+            p2 = rm.default_params(width=120, height=91, kernel=1)
+            m.set_params(p2)
+            assert m.render_rgba8().tobytes() == _single(rm, scene, p2).tobytes()
+    finally:
+        m.close()
+    cpu, _ = oracle.Scene(scene_path("default.txt")).render(oracle.default_params(**kw))
+    np.testing.assert_array_equal(want, oracle.quantize(cpu))
+
+
+def test_multi_into_device_memory_and_settings_per_rank(rm):
+    import torch
+    scene = rm.Scene(scene_path("menger2.txt"))
+    p = rm.default_params(width=160, height=101, kernel=2)
+    want = _single(rm, scene, p)
+    m = rm.MultiRenderer([0, 0])
+    try:
+        for r in range(2):
+            m.context(r).set_kernel_mode(False)          # the record walker on every rank
+        m.set_params(p)
+        m.set_scene(scene)
+        out = torch.zeros((p.height, p.width, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            out.zero_()
+            m.render_device(out.data_ptr())
+            assert out.cpu().numpy().tobytes() == want.tobytes()
+        assert m.context(0).counters()["compiled_kernel"] == 0
+    finally:
+        m.close()
+
+
+def test_multi_argument_errors(rm):
+    with pytest.raises(rm.RaymarchError, match="names a device twice"):
+        rm.MultiRenderer([0, 0], rm.MULTI_RCCL)
+    with pytest.raises(rm.RaymarchError, match="no HIP device"):
+        rm.MultiRenderer([0, 99])
+    m = rm.MultiRenderer([0])
+    try:
+        with pytest.raises(rm.RaymarchError, match="rm_multi_set_params has not been called"):
+            m.render_rgba8(out=np.zeros(4, np.uint8).ctypes.data)
+    finally:
+        m.close()
