@@ -840,6 +840,90 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     return kLatticeNext;
 }
 
+// ---- a lattice evaluated by a group of lanes (tile parts, trace_kernel.h) ----------------------------------------
+//
+// In the sixteenth parts of a split tile a sample owns 16 lanes (or 8, for a shadow ray of one of two lights): the lanes
+// of such a group hold the same point and would each walk the lattice level after level, every level waiting for the
+// last one's running value.  They share the walk instead.  The rows through the centre nearest to p -- the only rows
+// lattice_level can find in range -- are cut into chunks of three cells; the host lists the chunks of every level below
+// the coarsest behind the lattice's tables (program.cpp: a descriptor of kCoopChunkWords words per chunk: the level's
+// half width and 1 / spacing, origin and table of the row's two fixed axes, the three cells' coordinates and digit
+// masks, the running axis and the level).  Lane r of a group evaluates chunks r, r + C, ...: it finds the nearest
+// centres on the chunk's two fixed axes, and its three cells' -cross(p) with the reference's formula and operand order
+// (body.cpp:51-57) -- WITHOUT asking whether the row is in range: every cell of such a row is a cross of the lattice,
+// so its value can only be one the brute-force maximum sees as well.  The maxima per level meet in all lanes of the group
+// (group_max: four DPP steps), and lattice_level_known then replays lattice_level's decisions with them: same early
+// out, same condition for the nearest-centre argument, `run` raised by the level's maximum.  Complete for the same
+// reason as lattice_level: a cross of level l that beats `run` has two axis terms below tau, so (under the 0.45
+// condition) it lies on a row through the nearest centre, and those rows are evaluated in full.  Hence the same value
+// as the walk of one lane, up to the sign of a zero (a maximum over the same floats in another order).
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// Largest v among the lanes of the caller's group of `cw` consecutive lanes (cw = 8 or 16, aligned; all of them
+// executing): neighbours in the quad, the other quad of the half row, the other half of the 16-lane row.
+__device__ __forceinline__ float group_max(float v, bool whole_row) {
+    v = __builtin_fmaxf(v, dpp_lane<0xB1>(v));    // quad_perm [1, 0, 3, 2]
+    v = __builtin_fmaxf(v, dpp_lane<0x4E>(v));    // quad_perm [2, 3, 0, 1]
+    v = __builtin_fmaxf(v, dpp_lane<0x141>(v));   // row_half_mirror: lane i of 8 takes lane 7 - i
+    const float other_half = dpp_lane<0x140>(v);  // row_mirror: lane i of 16 takes lane 15 - i
+    return whole_row ? __builtin_fmaxf(v, other_half) : v;
+}
+
+// This lane's chunks of the lattice block `w` (in LDS) at p: the largest -cross(p) of its cells, per level (levels 1 and
+// 2; lattices of more levels are not evaluated this way), then the maximum over the group.  N_CHUNKS: descriptors of the
+// block; cw: lanes per group, 8 or 16.
+template <uint32_t N_CHUNKS>
+__device__ __forceinline__ void lattice_coop(const uint32_t *w, uint32_t chunk_table, V3 p, uint32_t cw, float &m1, float &m2) {
+    const uint32_t role = (threadIdx.x & 63u) & (cw - 1u);
+    m1 = m2 = -__builtin_inff();
+    for (uint32_t first = 0; first < N_CHUNKS; first += cw) {   // the same trip count for every lane of the wave
+        const uint32_t c = first + role;
+        const bool mine = c < N_CHUNKS;
+        const uint32_t *d = w + chunk_table + kCoopChunkWords * (mine ? c : 0u);
+        const float h = __uint_as_float(d[0]), inv = __uint_as_float(d[1]);
+        const uint32_t word = d[11], axis = word >> 24 & 3u, level = word >> 26 & 7u;
+        const float pa = axis == 0u ? p.y : p.x, pb = axis == 2u ? p.y : p.z;        // the row's fixed axes, in x, y, z order
+        const float pt = axis == 0u ? p.x : (axis == 1u ? p.y : p.z);                // the axis its cells run along
+        const int last = (int)d[7];
+        const int ia = nearest_index(pa, __uint_as_float(d[2]), inv, last), ib = nearest_index(pb, __uint_as_float(d[3]), inv, last);
+        const float da = __builtin_fabsf(pa - __uint_as_float(w[d[4] + (uint32_t)ia])) - h;
+        const float db = __builtin_fabsf(pb - __uint_as_float(w[d[5] + (uint32_t)ib])) - h;
+        const uint32_t oa = w[d[6] + (uint32_t)ia], ob = w[d[6] + (uint32_t)ib];
+        const uint32_t fixed_ones = oa | ob;
+        const float both = da + db;   // z runs: (dx + dy) + dz
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = __builtin_fabsf(pt - __uint_as_float(d[8 + k])) - h;
+            // dx + dy + dz in the reference's order: x runs (t + da) + db, y runs (da + t) + db -- the same sum, an addition
+            // of two floats does not depend on their order -- z runs (da + db) + t
+            const float sum = axis == 2u ? both + t : (t + da) + db;
+            const float dmin = __builtin_fminf(__builtin_fminf(t, da), db), dmax = __builtin_fmaxf(__builtin_fmaxf(t, da), db);
+            const float v = -(sum - dmin - dmax);
+            best = __builtin_fmaxf(best, ((word >> (8 * k) & 255u) & fixed_ones) ? -__builtin_inff() : v);
+        }
+        // two zero offsets at one subdivision step: no such sub-cube (lattice_level's !(ox & oy))
+        best = (mine && !(oa & ob)) ? best : -__builtin_inff();
+        m1 = __builtin_fmaxf(m1, level == 1u ? best : -__builtin_inff());
+        m2 = __builtin_fmaxf(m2, level == 2u ? best : -__builtin_inff());
+    }
+    m1 = group_max(m1, cw == 16u);
+    m2 = group_max(m2, cw == 16u);
+}
+
+// lattice_level's decisions for a level whose rows through the nearest centres are already evaluated: level_max is the
+// largest -cross(p) among them.
+__device__ __forceinline__ int lattice_level_known(float h, float inv, float eps, float level_max, float &run) {
+    if (!(run < h * 1.00001f + eps)) return kLatticeDone;
+    const float tau = eps - run;
+    if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
+    run = __builtin_fmaxf(run, level_max);
+    return kLatticeNext;
+}
+
 // lattice_fold at NP points with the work booked (distance-only walk)
 template <bool COUNT, int NP>
 __device__ __forceinline__ void lattice_sd(const uint32_t *w, ConstIndex g, uint32_t levels, uint32_t first_row,

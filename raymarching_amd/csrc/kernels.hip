@@ -154,12 +154,14 @@ __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
 }  // namespace
 
 hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream) {
+    (void)hipGetLastError();   // a launch reports its own error, not one an earlier failed call left behind
     const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
     hipLaunchKernelGGL(grid_kernel<false>, dim3((n_cells + 255u) / 256u), dim3(256), 0, stream, b);
     return hipGetLastError();
 }
 
 hipError_t launch_fill_grid(const GridBuild &b, hipStream_t stream) {
+    (void)hipGetLastError();
     const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
     hipLaunchKernelGGL(grid_kernel<true>, dim3((n_cells + 255u) / 256u), dim3(256), 0, stream, b);
     return hipGetLastError();
@@ -179,6 +181,7 @@ hipError_t launch_trace(const SceneView &sc, const FrameView &fr, bool wide_runs
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0) return hipSuccess;
+    (void)hipGetLastError();
     const uint32_t lds = lds_bytes(sc);
     if (wide_runs) {   // one sample per lane, one wave per workgroup
         const dim3 grid((sw + 7u) / 8u, (sh + 7u) / 8u, 1u);
@@ -196,6 +199,7 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sampl
                           hipStream_t stream) {
     const uint32_t rows = fr.band_count * fr.band_rows;
     if (fr.width == 0 || rows == 0) return hipSuccess;
+    (void)hipGetLastError();
     const dim3 grid((fr.width + 63u) / 64u, (rows + 3u) / 4u, 1u);
     hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, fr, colors, samples, out_f32, out_rgba8);
     return hipGetLastError();
@@ -204,6 +208,7 @@ hipError_t launch_resolve(const FrameView &fr, const Float4 *colors, const Sampl
 hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, float *sd, uint32_t *prim, float *sd_march,
                            hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(eval_sdf_kernel, dim3((n + 255u) / 256u), dim3(256), lds_bytes(sc), stream, sc, xyz, n, sd, prim, sd_march);
     return hipGetLastError();
 }

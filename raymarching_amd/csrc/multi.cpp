@@ -114,11 +114,12 @@ namespace {
 void release_buffers(rm_multi *m) {
     for (size_t r = 0; r < m->ranks.size(); r++) {
         Rank &k = m->ranks[r];
+        if (!k.shard) continue;
         (void)hipSetDevice(k.device);
         if (k.shard && !(m->stack && r == 0)) (void)hipFree(k.shard);
         k.shard = nullptr;
     }
-    if (!m->ranks.empty()) (void)hipSetDevice(m->ranks[0].device);
+    if (m->stack || m->frame) (void)hipSetDevice(m->ranks[0].device);
     if (m->stack) (void)hipFree(m->stack);
     if (m->frame) (void)hipFree(m->frame);
     m->stack = m->frame = nullptr;
@@ -321,9 +322,10 @@ int rm_multi_destroy(rm_multi *m) {
         if (k.comm && rccl().handle) (void)rccl().CommDestroy(k.comm);
     release_buffers(m);
     for (Rank &k : m->ranks) {
+        if (!k.ctx) continue;   // a rank whose device could not be opened (rm_multi_create undoing itself)
         (void)hipSetDevice(k.device);
         if (k.rendered) (void)hipEventDestroy(k.rendered);
-        if (k.ctx) (void)rm_destroy(k.ctx);
+        (void)rm_destroy(k.ctx);
     }
     if (m->gathered) {
         (void)hipSetDevice(m->ranks[0].device);
