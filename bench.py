@@ -520,6 +520,32 @@ def main():
                         "per synchronous call (rm_render_device / rm_render_rgba8 into page-locked / pageable memory)"}
         for hb in bufs:
             hb.free()
+    # ---- the one-process sharded path (rm_multi_*): four ranks, all on this GPU (shares gathered by copies; with distinct
+    # devices the same calls gather with RCCL send/recv), one frame at a time into device memory; after the timed region
+    native_multi = None
+    if world == 1 and not group and a.emulate_share <= 1 and not a.no_host_leg:
+        m = rm.MultiRenderer([local] * 4)
+        try:
+            m.set_params(params)
+            m.set_scene(scene)
+            whole_rows = rm.Rows(H, 0, 1, 1)
+            single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+            r.render_device(whole_rows, None, single.data_ptr())
+            out_m = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            for _ in range(4):
+                m.render_device(out_m.data_ptr())
+            n_m = max(8, min(a.steps, 50))
+            t1 = time.perf_counter()
+            for _ in range(n_m):
+                m.render_device(out_m.data_ptr())
+            multi_ms = (time.perf_counter() - t1) / n_m * 1e3
+            native_multi = {"ranks": 4, "devices": [local] * 4, "transport": "copies" if m.transport == rm.MULTI_COPY else "rccl",
+                            "frame_ms": round(multi_ms, 4), "frame_equals_single_launch": bool(torch.equal(out_m, single)),
+                            "note": "rm_multi_render_device: the frame's 4-row bands dealt to four contexts of this one GPU, shares gathered and "
+                                    "de-interleaved on rank 0, one frame at a time (a functional rehearsal of the one-process multi-GPU path, "
+                                    "not a scaling figure)"}
+        finally:
+            m.close()
     # ---- cold start: a fresh process uploads the scene and renders its first frame, with an empty cache directory
     # and again with what the first run left in it (compiled kernels, measured tile order)
     first = None
@@ -603,6 +629,7 @@ def main():
             "every_ray_marched": all_marched,
             "host_image": host,
             "first_frame": first,
+            "native_multi": native_multi,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "trace_kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
         }

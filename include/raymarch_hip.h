@@ -333,6 +333,18 @@ int rm_kernel_source_compiles(const char *source);
  * directory is kept below $RM_KERNEL_CACHE_MAX_MB (default 256) by deleting the files unused for longest. */
 int rm_set_kernel_cache_dir(const char *directory);
 
+/*
+ * Diagnostic (no counterpart in the reference; the frame is the same): with slot statistics on, every workgroup of a
+ * render leaves four words -- its tile-order entry (tile number in the low 27 bits; above them 0 for a whole tile,
+ * 1-4 a quarter, 5-20 a sixteenth of it), its duration in 10 ns ticks, the trip counts of its camera march (low 16
+ * bits) and of its shadow marches (high 16 bits; the longest ray of its wave each time, capped at 65535), and the low
+ * 32 bits of the 100 MHz clock at its start -- in launch order.  Tells which workgroups a frame waits
+ * for at its end, and whether they were marching a camera ray or shadow rays.  words: 4 * capacity_slots uint32
+ * (NULL to ask for *n_slots, the number of workgroups of the last render).  Not with rm_enqueue_device_static.
+ */
+int rm_set_slot_stats(rm_context *ctx, int enabled);
+int rm_get_slot_stats(rm_context *ctx, uint32_t *words, size_t capacity_slots, size_t *n_slots);
+
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);
 int rm_get_counters(rm_context *ctx, rm_counters *out);

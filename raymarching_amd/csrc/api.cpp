@@ -149,6 +149,9 @@ struct rm_context {
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
     DeviceArray<float> d_points, d_sd, d_camera;
+    DeviceArray<uint32_t> d_slot_stats;   // rm_set_slot_stats: four words per workgroup slot of the last render
+    bool slot_stats = false;
+    size_t slot_stats_slots = 0;
     DeviceArray<unsigned char> d_warm;   // target of the one-pixel launch that warms a freshly loaded kernel
     DeviceArray<uint32_t> d_prim, d_lattice, d_row_prim;
     DeviceArray<uint32_t> d_grid_cells, d_grid_entries;
@@ -450,6 +453,14 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
             fr.tile_cost = ctx->d_tile_cost.ptr;
         }
     }
+    ctx->slot_stats_slots = 0;
+    if (ctx->slot_stats && !static_samples && !refill) {
+        const size_t slots = pend.n_tiles + (fr.tile_order ? fr.extra_slots : 0u);
+        RM_HIP(ctx->d_slot_stats.reserve(4u * slots));
+        RM_HIP(hipMemsetAsync(ctx->d_slot_stats.ptr, 0, 4u * slots * sizeof(uint32_t), ctx->stream));
+        fr.slot_stats = ctx->d_slot_stats.ptr;
+        ctx->slot_stats_slots = slots;
+    }
     rmdev::WorkCounters *d_cnt = nullptr;
     if (ctx->counting && static_samples) return fail(RM_ERR_STATE, "rm_enqueue_device_static: work counting needs allocated buffers (rm_set_counting(ctx, 0) first)");
     if (ctx->counting) {
@@ -718,6 +729,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_tile_order.release(); ctx->d_tile_cost.release(); ctx->d_band_list.release(); ctx->h_tiles.release();
     ctx->d_grid_cells.release(); ctx->d_grid_entries.release(); ctx->d_grid_total.release(); ctx->d_grid_bound.release();
     ctx->d_warm.release();
+    ctx->d_slot_stats.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -1131,6 +1143,25 @@ int rm_get_tile_costs(rm_context *ctx, uint32_t *ticks, size_t capacity, uint32_
         if (capacity < n) return fail(RM_ERR_INVALID, "rm_get_tile_costs: capacity too small");
         RM_HIP(hipSetDevice(ctx->device));
         RM_HIP(hipMemcpy(ticks, ctx->d_tile_cost.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return RM_OK;
+}
+
+int rm_set_slot_stats(rm_context *ctx, int enabled) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    ctx->slot_stats = enabled != 0;
+    return RM_OK;
+}
+
+int rm_get_slot_stats(rm_context *ctx, uint32_t *words, size_t capacity_slots, size_t *n_slots) {
+    if (!ctx || !n_slots) return fail(RM_ERR_INVALID, "rm_get_slot_stats: null argument");
+    *n_slots = ctx->slot_stats_slots;
+    if (words) {
+        if (capacity_slots < ctx->slot_stats_slots) return fail(RM_ERR_INVALID, "rm_get_slot_stats: capacity too small");
+        RM_HIP(hipSetDevice(ctx->device));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->slot_stats_slots)
+            RM_HIP(hipMemcpy(words, ctx->d_slot_stats.ptr, 4u * ctx->slot_stats_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return RM_OK;
 }

@@ -95,10 +95,10 @@ int group_tests_mode() {
 }
 bool group_tests_enabled() { return group_tests_mode() != 0; }
 
+
 struct Emitter {
     const HostProgram &prog;
     bool track;
-    bool coop = false;   // distance walk at one point held by a whole group of lanes: lattices are walked by the group (lattice_coop)
     std::string s;
     unsigned evals = 0, flops = 0;    // work of the leaves emitted into the current block, not yet booked
     char buf[640];
@@ -180,33 +180,6 @@ struct Emitter {
             std::snprintf(buf, sizeof buf,
                           "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) lattice_fold<true, false>(lds.lattice + %uu, (ConstIndex)sc.lattice + %uu, %uu, %uu, p[n], %s[n], %s[n], evals_unused[n]);\n",
                           r.a[1], r.a[1], r.a[0], r.prim, acc(depth).c_str(), accp(depth).c_str());
-        } else if (coop && prog.lattice[r.a[1] + kLatCoopChunks] != 0u) {
-            // the group's lanes evaluate the rows of the finer levels together; level 0 (one cross, in registers) and the
-            // decisions of the walk are every lane's own, with the same values in all lanes of the group
-            const uint32_t off = r.a[1], levels = r.a[0];
-            const uint32_t *w = prog.lattice.data() + off;
-            std::snprintf(buf, sizeof buf,
-                          "    {\n        const uint32_t *w = lds.lattice + %uu;\n        const ConstIndex g = (ConstIndex)sc.lattice + %uu;\n"
-                          "        const float eps = 2e-6f * (__builtin_fabsf(p[0].x) + __builtin_fabsf(p[0].y) + __builtin_fabsf(p[0].z) + %s);\n"
-                          "        float run = %s[0], m1, m2;\n        uint32_t evals = 0;\n"
-                          "        lattice_coop<%uu>(w, %uu, p[0], cw, m1, m2);\n        int state = kLatticeNext;\n        do {\n"
-                          "            state = lattice_level<1, false>(w + %uu, %s, %s, %s, %s, %s, p[0], eps, run, evals);\n"
-                          "            if (state != kLatticeNext) break;\n",
-                          off, off, lit(as_float(w[2])).c_str(), acc(depth).c_str(), w[kLatCoopChunks], w[kLatCoopOffset], w[kLatOffset],
-                          lit(as_float(w[kLatHalf])).c_str(), lit(as_float(w[kLatInvSpacing])).c_str(), lit(as_float(w[kLatOrigin])).c_str(),
-                          lit(as_float(w[kLatOrigin + 1])).c_str(), lit(as_float(w[kLatOrigin + 2])).c_str());
-            s += buf;
-            for (uint32_t l = 1; l < levels; l++) {
-                std::snprintf(buf, sizeof buf,
-                              "            state = lattice_level_known(%s, %s, eps, m%u, run);\n            if (state != kLatticeNext) break;\n",
-                              lit(as_float(w[kLatHalf + l])).c_str(), lit(as_float(w[kLatInvSpacing + l])).c_str(), l);
-                s += buf;
-            }
-            std::snprintf(buf, sizeof buf,
-                          "        } while (false);\n"
-                          "        if (state == kLatticeGeneral) { uint32_t no_prim1 = kNoPrim; lattice_fold<false, false>(w, g, %uu, 0u, p[0], run, no_prim1, evals); }\n"
-                          "        %s[0] = run;\n    }\n",
-                          levels, acc(depth).c_str());
         } else {
             // the lattice's header fields go into the code as literals, its levels are unrolled
             const uint32_t off = r.a[1], levels = r.a[0];
@@ -230,7 +203,7 @@ struct Emitter {
             }
             std::snprintf(buf, sizeof buf,
                           "        } while (false);\n"
-                          "        if (state == kLatticeGeneral) { uint32_t no_prim = kNoPrim; lattice_fold<false, COUNT>(w, g, %uu, 0u, p[n], run, no_prim, evals); }\n"
+                          "        if (state == kLatticeGeneral) lattice_fold_scans<COUNT>(w, g, %uu, p[n], run, evals);\n"
                           "        %s[n] = run;\n"
                           "        if (COUNT) { work[n].evals += evals; work[n].flops += kFlopsCross * evals; }\n    }\n",
                           levels, acc(depth).c_str());
@@ -465,8 +438,8 @@ struct Emitter {
 };
 
 // body of sd() (track = false) or surface() (track = true)
-std::string emit_body(const HostProgram &prog, bool track, bool coop = false) {
-    Emitter e{ prog, track, coop, std::string(), 0, 0, { 0 }, false };
+std::string emit_body(const HostProgram &prog, bool track) {
+    Emitter e{ prog, track, std::string(), 0, 0, { 0 }, false };
     std::vector<Item> top;
     parse_children(prog.recs, 0, top);
     e.declare(0, prog.root_identity);
@@ -483,22 +456,7 @@ std::string emit_body(const HostProgram &prog, bool track, bool coop = false) {
 
 std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting, bool refill) {
     std::string s;
-    // a lattice that a group of lanes can walk together (two or three levels): the scene gets a second distance walk for
-    // the marches of tile parts (trace_kernel.h)
-    bool coop = false;
-    for (const Rec &r : prog.recs)
-        if ((r.flags & 15u) == REC_LATTICE && prog.lattice[r.a[1] + kLatCoopChunks] != 0u) coop = true;
-    if (const char *env = std::getenv("RM_COOP")) coop = coop && std::atoi(env) != 0;   // A/B runs (the source, and with it the cache key, differs)
     s += "#include \"trace_refill.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
-    s += std::string("static constexpr bool kCoop = ") + (coop ? "true" : "false") + ";\n";
-    if (coop) {
-        s += "// sd<1, false> at a point that all lanes of a group of cw (8 or 16) consecutive lanes hold\n"
-             "static __device__ __forceinline__ void sd_coop(const SceneView &sc, const Lds &lds, const V3 (&p)[1], float (&out_sd)[1],\n"
-             "                                               const float (&cap)[1], bool (&colourless)[1], uint32_t cw) {\n"
-             "    constexpr int NP = 1;\n    constexpr bool COUNT = false;\n    Work work[1] = {};\n";
-        s += emit_body(prog, false, true);
-        s += "}\n\n";
-    }
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
          "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {\n";
     s += emit_body(prog, false);

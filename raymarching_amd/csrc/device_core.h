@@ -715,6 +715,73 @@ __device__ __forceinline__ int nearest_index(float p, float origin, float inv_sp
     return (int)__builtin_fminf(__builtin_fmaxf(u, 0.0f), (float)last);
 }
 
+// One level of the lattice by ranges: on every axis the centres whose axis term is below tau, then every row whose two fixed
+// indices lie in their ranges (and name a row), all n cells of it.  The rare walk of points deep inside material, written
+// for size, not for speed: one body for the three directions a row can run in, the direction a loop variable.  The cells'
+// values are the reference's: x runs (t + d1) + d2, y runs (d1 + t) + d2 -- the same sum, an addition of two floats does
+// not depend on their order -- z runs (d1 + d2) + t, minimum and maximum of the three terms, sum - min - max.
+// tab: the level's X table, followed by Y, Z and ONES.
+__device__ __forceinline__ float lattice_scan_level(const uint32_t *tab, int n, V3 p, float h, float inv, float tau, float run, uint32_t &n_evals) {
+    const uint32_t *ONES = tab + 3 * n;
+    int lo0, hi0, lo1, hi1, lo2, hi2;
+    axis_range(tab, n, p.x, h, inv, tau, lo0, hi0);
+    axis_range(tab + n, n, p.y, h, inv, tau, lo1, hi1);
+    axis_range(tab + 2 * n, n, p.z, h, inv, tau, lo2, hi2);
+    _Pragma("nounroll") for (int along = 0; along < 3; ++along) {
+        // the row's fixed axes a < b, in x, y, z order
+        const uint32_t *A = tab + (along == 0 ? n : 0), *B = tab + (along == 2 ? n : 2 * n), *T = tab + along * n;
+        const float pa = along == 0 ? p.y : p.x, pb = along == 2 ? p.y : p.z, pt = along == 0 ? p.x : (along == 1 ? p.y : p.z);
+        const int loa = along == 0 ? lo1 : lo0, hia = along == 0 ? hi1 : hi0, lob = along == 2 ? lo1 : lo2, hib = along == 2 ? hi1 : hi2;
+        _Pragma("nounroll") for (int i = loa; i <= hia; ++i) {
+            _Pragma("nounroll") for (int j = lob; j <= hib; ++j) {
+                const uint32_t fixed_ones = ONES[i] | ONES[j];
+                if (ONES[i] & ONES[j]) continue;   // two zero offsets at one subdivision step: no such sub-cube
+                const float da = axis_term(A, i, pa, h), db = axis_term(B, j, pb, h), both = da + db;
+                _Pragma("nounroll") for (int k = 0; k < n; ++k) {
+                    const float t = axis_term(T, k, pt, h);
+                    const float sum = along == 2 ? both + t : (t + da) + db;
+                    const float dmin = __builtin_fminf(__builtin_fminf(t, da), db), dmax = __builtin_fmaxf(__builtin_fmaxf(t, da), db);
+                    run = __builtin_fmaxf(run, (ONES[k] & fixed_ones) ? -__builtin_inff() : -(sum - dmin - dmax));
+                }
+                n_evals += (uint32_t)n;
+            }
+        }
+    }
+    return run;
+}
+
+// The sum of 3^position over the bits of a digit mask: what takes an index with digit 1 at those positions to the index
+// with digit 0 there.
+// n: centres per axis of the level, 3^(digit positions).
+__device__ __forceinline__ int digits_to_zero(uint32_t mask, int n) {
+    int sum = 0;
+    for (int power = 1; power < n; power *= 3, mask >>= 1) sum += (mask & 1u) ? power : 0;
+    return sum;
+}
+
+// One cross of level l (n = 3^l centres per axis) on each of the three rows through the centres nearest to p: the row's
+// two fixed indices are the nearest ones (if they name a row: no digit position where both have digit 1), the running index
+// is the nearest one with the digits that clash with the fixed indices set to 0, which names a cross of the lattice.
+// Returns the largest -cross(p) of the three, each with the reference's operands in their places: values of real crosses,
+// never above the lattice's maximum -- and where p lies in a tunnel of this level, or next to one, a bar of one of these
+// three crosses is that tunnel (the bars are endless: every cross of a row carries the row's bar), so the value is the
+// lattice's own there.
+__device__ __forceinline__ float lattice_nearest_rows(const uint32_t *w, ConstIndex g, uint32_t l, int n, V3 p) {
+    const ConstFloats gf = (ConstFloats)g;
+    const float h = gf[kLatHalf + l], inv = gf[kLatInvSpacing + l];
+    const uint32_t *X = w + g[kLatOffset + l], *Y = X + n, *Z = Y + n, *ONES = Z + n;
+    const int ix = nearest_index(p.x, gf[kLatOrigin + 3 * l], inv, n - 1);
+    const int iy = nearest_index(p.y, gf[kLatOrigin + 3 * l + 1], inv, n - 1);
+    const int iz = nearest_index(p.z, gf[kLatOrigin + 3 * l + 2], inv, n - 1);
+    const float dx = axis_term(X, ix, p.x, h), dy = axis_term(Y, iy, p.y, h), dz = axis_term(Z, iz, p.z, h);
+    const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
+    float best = -__builtin_inff();
+    if (!(ox & oy)) best = __builtin_fmaxf(best, -cross_value(dx, dy, axis_term(Z, iz - digits_to_zero(oz & (ox | oy), n), p.z, h)));
+    if (!(ox & oz)) best = __builtin_fmaxf(best, -cross_value(dx, axis_term(Y, iy - digits_to_zero(oy & (ox | oz), n), p.y, h), dz));
+    if (!(oy & oz)) best = __builtin_fmaxf(best, -cross_value(axis_term(X, ix - digits_to_zero(ox & (oy | oz), n), p.x, h), dy, dz));
+    return best;
+}
+
 template <bool TRACK, bool COUNT>
 __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, uint32_t levels, uint32_t first_row, V3 p,
                                              float &acc, uint32_t &acc_prim, uint32_t &n_evals) {
@@ -725,11 +792,27 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, ui
     const float eps = 2e-6f * bound;   // > 8x the worst rounding of dx + dy + dz - min - max at this magnitude
     float run = acc;
     int n = 1;
+    bool raised = false;
     for (uint32_t l = 0; l < levels; ++l, n *= 3) {
         const float h = gf[kLatHalf + l];
         if (!(run < h * 1.00001f + eps)) break;   // no cross this fine can beat the running value
-        const float tau = eps - run;
+        float tau = eps - run;
         const float inv = gf[kLatInvSpacing + l];
+        if (!((h + tau) * inv <= 0.45f) && !raised) {
+            // More than one centre per axis could be in range at this level: the running value is far below what the
+            // lattice is worth at p -- the usual cause is a point in one of the fine tunnels, a long way from the coarse
+            // ones, where the list's value so far is minus the depth inside the sponge's box.  Before scanning ranges of
+            // centres, one cross of each row through the nearest centres of this and of every finer level is folded
+            // (lattice_nearest_rows): each is a cross of the lattice, so the maximum cannot overshoot, and in a tunnel one
+            // of them carries the tunnel's own (small) value, after which the nearest-centre argument holds again on
+            // every level.  Once per walk; a point that is really deep inside material still takes the scans below.
+            raised = true;
+            int m = n;
+            for (uint32_t fine = l; fine < levels; ++fine, m *= 3) run = __builtin_fmaxf(run, lattice_nearest_rows(w, g, fine, m, p));
+            if (COUNT) n_evals += 3u * (levels - l);
+            if (!(run < h * 1.00001f + eps)) break;
+            tau = eps - run;
+        }
         const uint32_t offset = g[kLatOffset + l];
         const uint32_t *X = w + offset;
         const uint32_t *Y = X + n;
@@ -763,41 +846,30 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, ui
             }
             continue;
         }
-        int lox, hix, loy, hiy, loz, hiz;
-        axis_range(X, n, p.x, h, inv, tau, lox, hix);
-        axis_range(Y, n, p.y, h, inv, tau, loy, hiy);
-        axis_range(Z, n, p.z, h, inv, tau, loz, hiz);
-        const bool bx = lox <= hix, by = loy <= hiy, bz = loz <= hiz;
-        if (bx && by) {
-            for (int i = lox; i <= hix; ++i)
-                for (int j = loy; j <= hiy; ++j) {
-                    const uint32_t oi = ONES[i], oj = ONES[j];
-                    if (oi & oj) continue;
-                    run = lattice_row<2>((const float *)Z, ONES, n, p.z, h, axis_term(X, i, p.x, h), axis_term(Y, j, p.y, h), oi | oj, run);
-                    if (COUNT) n_evals += n;
-                }
-        }
-        if (bx && bz) {
-            for (int i = lox; i <= hix; ++i)
-                for (int k = loz; k <= hiz; ++k) {
-                    const uint32_t oi = ONES[i], ok = ONES[k];
-                    if (oi & ok) continue;
-                    run = lattice_row<1>((const float *)Y, ONES, n, p.y, h, axis_term(X, i, p.x, h), axis_term(Z, k, p.z, h), oi | ok, run);
-                    if (COUNT) n_evals += n;
-                }
-        }
-        if (by && bz) {
-            for (int j = loy; j <= hiy; ++j)
-                for (int k = loz; k <= hiz; ++k) {
-                    const uint32_t oj = ONES[j], ok = ONES[k];
-                    if (oj & ok) continue;
-                    run = lattice_row<0>((const float *)X, ONES, n, p.x, h, axis_term(Y, j, p.y, h), axis_term(Z, k, p.z, h), oj | ok, run);
-                    if (COUNT) n_evals += n;
-                }
-        }
+        run = lattice_scan_level(X, n, p, h, inv, tau, run, n_evals);
     }
     if (TRACK) acc_prim = (acc < run) ? first_row : acc_prim;   // all crosses of a lattice share one colour
     acc = run;
+}
+
+// The lattice's exact maximum by the shortest code there is for it: every level's nearest rows first (values of real
+// crosses, which bring `run` close to the lattice's value), then every level by ranges.  What the kernels generated for
+// a scene fall back to from the rare level their nearest-centre walk cannot decide (a point deep inside material): it
+// sits in every copy of the scene's walk, so its size counts and its speed does not.
+template <bool COUNT>
+__device__ __forceinline__ void lattice_fold_scans(const uint32_t *w, ConstIndex g, uint32_t levels, V3 p, float &run, uint32_t &n_evals) {
+    const ConstFloats gf = (ConstFloats)g;
+    const float eps = 2e-6f * (__builtin_fabsf(p.x) + __builtin_fabsf(p.y) + __builtin_fabsf(p.z) + gf[2]);
+    int n = 1;
+    _Pragma("nounroll") for (uint32_t l = 0; l < levels; ++l, n *= 3) run = __builtin_fmaxf(run, lattice_nearest_rows(w, g, l, n, p));
+    uint32_t evals = 3u * levels;
+    n = 1;
+    _Pragma("nounroll") for (uint32_t l = 0; l < levels; ++l, n *= 3) {
+        const float h = gf[kLatHalf + l];
+        if (!(run < h * 1.00001f + eps)) break;   // no cross this fine can beat the running value
+        run = lattice_scan_level(w + g[kLatOffset + l], n, p, h, gf[kLatInvSpacing + l], eps - run, run, evals);
+    }
+    if (COUNT) n_evals += evals;
 }
 
 // One level of lattice_fold with everything about the level known when the kernel is compiled (the
@@ -805,7 +877,7 @@ __device__ __forceinline__ void lattice_fold(const uint32_t *w, ConstIndex g, ui
 // half-width h, 1 / spacing, the first centre on each axis; `tab` = the level's X table in LDS.
 // Returns kLatticeNext to go on with the next level, kLatticeDone when the walk ends here, and
 // kLatticeGeneral in the rare case that needs the general scan (p deep inside material): the caller
-// then runs lattice_fold, which repeats the earlier levels to no effect (max is idempotent, and they
+// then runs lattice_fold_scans, which repeats the earlier levels to no effect (max is idempotent, and they
 // pass its early-out because coarser levels have larger half-widths).
 constexpr int kLatticeDone = 0, kLatticeNext = 1, kLatticeGeneral = 2;
 
@@ -813,8 +885,8 @@ template <int N, bool COUNT>
 __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float inv, float x0, float y0, float z0, V3 p, float eps,
                                              float &run, uint32_t &n_evals) {
     if (!(run < h * 1.00001f + eps)) return kLatticeDone;
-    const float tau = eps - run;
-    if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
+    float tau = eps - run;
+    if (N == 1 && !((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
     const float *X = (const float *)tab, *Y = X + N, *Z = Y + N;
     const uint32_t *ONES = tab + 3 * N;
     if (COUNT) n_evals += 3;
@@ -831,96 +903,37 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     const int ix = nearest_index(p.x, x0, inv, N - 1), iy = nearest_index(p.y, y0, inv, N - 1), iz = nearest_index(p.z, z0, inv, N - 1);
     const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
     const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
+    if (!((h + tau) * inv <= 0.45f)) {
+        // More than one centre per axis could be in range: the running value is far below what this level is worth at p
+        // (in a fine tunnel, away from the coarse ones, it is still minus the depth inside the sponge's box).  One cross
+        // of each row through the nearest centres is folded first -- see lattice_nearest_rows: values of real crosses, so
+        // the maximum cannot overshoot -- which as a rule leaves the nearest-centre argument valid for this level
+        // after all; where it does not, the caller takes the general walk.
+        float best = -__builtin_inff();
+        if (!(ox & oy)) {
+            const uint32_t clash = oz & (ox | oy);
+            best = __builtin_fmaxf(best, -cross_value(dx, dy, clash ? __builtin_fabsf(p.z - Z[iz - digits_to_zero(clash, N)]) - h : dz));
+        }
+        if (!(ox & oz)) {
+            const uint32_t clash = oy & (ox | oz);
+            best = __builtin_fmaxf(best, -cross_value(dx, clash ? __builtin_fabsf(p.y - Y[iy - digits_to_zero(clash, N)]) - h : dy, dz));
+        }
+        if (!(oy & oz)) {
+            const uint32_t clash = ox & (oy | oz);
+            best = __builtin_fmaxf(best, -cross_value(clash ? __builtin_fabsf(p.x - X[ix - digits_to_zero(clash, N)]) - h : dx, dy, dz));
+        }
+        if (COUNT) n_evals += 3;
+        run = __builtin_fmaxf(run, best);
+        if (!(run < h * 1.00001f + eps)) return kLatticeDone;
+        tau = eps - run;
+        if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
+    }
     const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
     const bool rz = bx && by && !(ox & oy), ry = bx && bz && !(ox & oz), rx = by && bz && !(oy & oz);
     run = lattice_rows<2, COUNT>(rz, Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
     run = lattice_rows<1, COUNT>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
     run = lattice_rows<0, COUNT>(rx, X, ONES, N, p.x, h, dy, dz, oy | oz, run);
     if (COUNT) n_evals += (uint32_t)N * ((rz ? 1u : 0u) + (ry ? 1u : 0u) + (rx ? 1u : 0u));
-    return kLatticeNext;
-}
-
-// ---- a lattice evaluated by a group of lanes (tile parts, trace_kernel.h) ----------------------------------------
-//
-// In the sixteenth parts of a split tile a sample owns 16 lanes (or 8, for a shadow ray of one of two lights): the lanes
-// of such a group hold the same point and would each walk the lattice level after level, every level waiting for the
-// last one's running value.  They share the walk instead.  The rows through the centre nearest to p -- the only rows
-// lattice_level can find in range -- are cut into chunks of three cells; the host lists the chunks of every level below
-// the coarsest behind the lattice's tables (program.cpp: a descriptor of kCoopChunkWords words per chunk: the level's
-// half width and 1 / spacing, origin and table of the row's two fixed axes, the three cells' coordinates and digit
-// masks, the running axis and the level).  Lane r of a group evaluates chunks r, r + C, ...: it finds the nearest
-// centres on the chunk's two fixed axes, and its three cells' -cross(p) with the reference's formula and operand order
-// (body.cpp:51-57) -- WITHOUT asking whether the row is in range: every cell of such a row is a cross of the lattice,
-// so its value can only be one the brute-force maximum sees as well.  The maxima per level meet in all lanes of the group
-// (group_max: four DPP steps), and lattice_level_known then replays lattice_level's decisions with them: same early
-// out, same condition for the nearest-centre argument, `run` raised by the level's maximum.  Complete for the same
-// reason as lattice_level: a cross of level l that beats `run` has two axis terms below tau, so (under the 0.45
-// condition) it lies on a row through the nearest centre, and those rows are evaluated in full.  Hence the same value
-// as the walk of one lane, up to the sign of a zero (a maximum over the same floats in another order).
-template <int CTRL>
-__device__ __forceinline__ float dpp_lane(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
-// Largest v among the lanes of the caller's group of `cw` consecutive lanes (cw = 8 or 16, aligned; all of them
-// executing): neighbours in the quad, the other quad of the half row, the other half of the 16-lane row.
-__device__ __forceinline__ float group_max(float v, bool whole_row) {
-    v = __builtin_fmaxf(v, dpp_lane<0xB1>(v));    // quad_perm [1, 0, 3, 2]
-    v = __builtin_fmaxf(v, dpp_lane<0x4E>(v));    // quad_perm [2, 3, 0, 1]
-    v = __builtin_fmaxf(v, dpp_lane<0x141>(v));   // row_half_mirror: lane i of 8 takes lane 7 - i
-    const float other_half = dpp_lane<0x140>(v);  // row_mirror: lane i of 16 takes lane 15 - i
-    return whole_row ? __builtin_fmaxf(v, other_half) : v;
-}
-
-// This lane's chunks of the lattice block `w` (in LDS) at p: the largest -cross(p) of its cells, per level (levels 1 and
-// 2; lattices of more levels are not evaluated this way), then the maximum over the group.  N_CHUNKS: descriptors of the
-// block; cw: lanes per group, 8 or 16.
-template <uint32_t N_CHUNKS>
-__device__ __forceinline__ void lattice_coop(const uint32_t *w, uint32_t chunk_table, V3 p, uint32_t cw, float &m1, float &m2) {
-    const uint32_t role = (threadIdx.x & 63u) & (cw - 1u);
-    m1 = m2 = -__builtin_inff();
-    for (uint32_t first = 0; first < N_CHUNKS; first += cw) {   // the same trip count for every lane of the wave
-        const uint32_t c = first + role;
-        const bool mine = c < N_CHUNKS;
-        const uint32_t *d = w + chunk_table + kCoopChunkWords * (mine ? c : 0u);
-        const float h = __uint_as_float(d[0]), inv = __uint_as_float(d[1]);
-        const uint32_t word = d[11], axis = word >> 24 & 3u, level = word >> 26 & 7u;
-        const float pa = axis == 0u ? p.y : p.x, pb = axis == 2u ? p.y : p.z;        // the row's fixed axes, in x, y, z order
-        const float pt = axis == 0u ? p.x : (axis == 1u ? p.y : p.z);                // the axis its cells run along
-        const int last = (int)d[7];
-        const int ia = nearest_index(pa, __uint_as_float(d[2]), inv, last), ib = nearest_index(pb, __uint_as_float(d[3]), inv, last);
-        const float da = __builtin_fabsf(pa - __uint_as_float(w[d[4] + (uint32_t)ia])) - h;
-        const float db = __builtin_fabsf(pb - __uint_as_float(w[d[5] + (uint32_t)ib])) - h;
-        const uint32_t oa = w[d[6] + (uint32_t)ia], ob = w[d[6] + (uint32_t)ib];
-        const uint32_t fixed_ones = oa | ob;
-        const float both = da + db;   // z runs: (dx + dy) + dz
-        float best = -__builtin_inff();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float t = __builtin_fabsf(pt - __uint_as_float(d[8 + k])) - h;
-            // dx + dy + dz in the reference's order: x runs (t + da) + db, y runs (da + t) + db -- the same sum, an addition
-            // of two floats does not depend on their order -- z runs (da + db) + t
-            const float sum = axis == 2u ? both + t : (t + da) + db;
-            const float dmin = __builtin_fminf(__builtin_fminf(t, da), db), dmax = __builtin_fmaxf(__builtin_fmaxf(t, da), db);
-            const float v = -(sum - dmin - dmax);
-            best = __builtin_fmaxf(best, ((word >> (8 * k) & 255u) & fixed_ones) ? -__builtin_inff() : v);
-        }
-        // two zero offsets at one subdivision step: no such sub-cube (lattice_level's !(ox & oy))
-        best = (mine && !(oa & ob)) ? best : -__builtin_inff();
-        m1 = __builtin_fmaxf(m1, level == 1u ? best : -__builtin_inff());
-        m2 = __builtin_fmaxf(m2, level == 2u ? best : -__builtin_inff());
-    }
-    m1 = group_max(m1, cw == 16u);
-    m2 = group_max(m2, cw == 16u);
-}
-
-// lattice_level's decisions for a level whose rows through the nearest centres are already evaluated: level_max is the
-// largest -cross(p) among them.
-__device__ __forceinline__ int lattice_level_known(float h, float inv, float eps, float level_max, float &run) {
-    if (!(run < h * 1.00001f + eps)) return kLatticeDone;
-    const float tau = eps - run;
-    if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
-    run = __builtin_fmaxf(run, level_max);
     return kLatticeNext;
 }
 

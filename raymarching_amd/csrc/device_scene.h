@@ -91,21 +91,13 @@ struct Sample { float light; uint32_t prim; };
 // most one digit equal to 1 (the 20 sub-cubes kept at every subdivision step).  The host
 // verifies this bit for bit on the node list itself (program.cpp) before emitting LATTICE.
 // A block of 32-bit words per lattice:
-//   [0] levels  [1] [3] chunk descriptors (below)  [2] magnitude bound (float)  [4..11] half[l]  [12..19] 1/spacing[l]
+//   [0] levels  [2] magnitude bound (float)  [4..11] half[l]  [12..19] 1/spacing[l]
 //   [20..27] word offset of level l's tables: X[3^l], Y[3^l], Z[3^l], ONES[3^l]
 //   [28..51] X_l[0], Y_l[0], Z_l[0] per level (saves a dependent table read in the index estimate)
 //   ONES[i] = bit mask of the digit positions where index i has digit 1.
 constexpr uint32_t kLatticeMaxLevels = 8;
 constexpr uint32_t kLatHalf = 4, kLatInvSpacing = 12, kLatOffset = 20, kLatOrigin = 28, kLatHeaderWords = 52;
 constexpr uint32_t kLatticeMaxWords = 12288;   // 48 KiB of LDS per workgroup at most
-// Lattices of two or three levels also carry, behind their tables, a descriptor per chunk of three cells of the rows
-// below the coarsest level, for the walk that a group of lanes shares (device_core.h: lattice_coop):
-//   [0] half  [1] 1/spacing  [2] [3] first centre on the row's two fixed axes  [4] [5] word offsets of those axes'
-//   tables  [6] of the level's ONES table  [7] 3^level - 1  [8..10] the three cells' coordinates on the running axis
-//   [11] their digit masks (8 bits each), the running axis (bits 24-25) and the level (bits 26-28)
-// header word [1] = word offset of the first descriptor (a multiple of 4), [3] = their number (0: none).
-constexpr uint32_t kCoopChunkWords = 12;
-constexpr uint32_t kLatCoopOffset = 1, kLatCoopChunks = 3;
 
 constexpr uint32_t kMaxDepth = 8;           // nested lists below the root
 constexpr uint32_t kNoPrim = 0xffffffffu;   // "colour of an empty list": black
@@ -206,6 +198,11 @@ struct FrameView {
     // the lighting is zero either way) and shadow rays stop once past their light; zero: every sample and
     // ray does the reference's full work, which is what work counts that are compared with the reference's need.
     uint32_t skip_unlit;
+    // Diagnostic (null: off): four words per workgroup slot of the launch -- its tile_order entry, its duration in 10 ns
+    // ticks, the iterations its wave spent in the camera march (low 16 bits) and in its shadow marches (high 16 bits; the
+    // loops' trip counts: the wave's longest ray each time), and the clock at its start.  Tells which workgroups a frame
+    // waits for, and what for.
+    uint32_t *slot_stats;
     // Tile of the kernel whose lanes take the tile's next sample when their own is finished (trace_refill.h):
     // 2^refill_w_log2 x 2^refill_h_log2 samples, both at least 8.
     uint32_t refill_w_log2, refill_h_log2;

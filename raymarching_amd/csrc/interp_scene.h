@@ -20,7 +20,6 @@ namespace rmdev {
 // accumulator" needs no case of its own; an empty list keeps +inf / no colour.
 
 struct InterpretedScene {
-    static constexpr bool kCoop = false;   // no evaluator shared by a group of lanes (trace_kernel.h: tile parts)
     template <int NP, bool COUNT>
     static __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
                                              Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {

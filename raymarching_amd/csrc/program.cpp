@@ -158,41 +158,6 @@ struct LatticeMatcher {
                 for (float v : *t) bound = std::fmax(bound, std::fabs((double)v));
         }
         put_f(base + 2, (float)(3.0 * bound + 3.0 * half[0]));
-        // Chunk descriptors for the walk shared by a group of lanes (device_core.h: lattice_coop), lattices of two or
-        // three levels only: per level below the coarsest and per axis, the row's cells three at a time.
-        if (n >= 2 && n <= 3) {
-            while ((out.size() - base) % 4u) out.push_back(0u);
-            out[base + kLatCoopOffset] = (uint32_t)out.size() - base;
-            uint32_t chunks = 0;
-            for (uint32_t l = 1; l < n; l++) {
-                const uint32_t m = pow3(l), tables = out[base + kLatOffset + l];
-                const float spacing = (X[l].back() - X[l].front()) / (float)(X[l].size() - 1);
-                const std::vector<float> *axes[3] = { &X[l], &Y[l], &Z[l] };
-                for (uint32_t axis = 0; axis < 3; axis++) {
-                    const uint32_t fa = axis == 0 ? 1u : 0u, fb = axis == 2 ? 1u : 2u;   // the row's fixed axes, in x, y, z order
-                    for (uint32_t first = 0; first < m; first += 3) {
-                        uint32_t d[kCoopChunkWords] = {};
-                        d[0] = bits_of(half[l]);
-                        d[1] = bits_of(1.0f / spacing);
-                        d[2] = bits_of(axes[fa]->front());
-                        d[3] = bits_of(axes[fb]->front());
-                        d[4] = tables + fa * m;
-                        d[5] = tables + fb * m;
-                        d[6] = tables + 3u * m;
-                        d[7] = m - 1u;
-                        uint32_t word = axis << 24 | l << 26;
-                        for (uint32_t k = 0; k < 3; k++) {
-                            d[8 + k] = bits_of((*axes[axis])[first + k]);
-                            word |= out[base + tables + 3u * m + first + k] << (8u * k);   // the cell's digit mask: l <= 2 bits
-                        }
-                        d[11] = word;
-                        out.insert(out.end(), d, d + kCoopChunkWords);
-                        chunks++;
-                    }
-                }
-            }
-            out[base + kLatCoopChunks] = chunks;
-        }
         return base;
     }
 };

@@ -33,11 +33,12 @@ __device__ __forceinline__ V3 from_lane(V3 v, uint32_t from) { return v3(from_la
 // of length sd its value is at least -roundings.  past_light covers both: 1.8e-7 of the coordinates'
 // magnitude per step for the roundings of p (three components, half an ulp each), 3e-5 of it for the SDF.
 // Camera rays have no light to pass: SHADOW = false leaves the test out (to_light and past_light are not read).
+// Returns the number of times the calling lane went round the loop.
 template <class Scene, int kPts, bool COUNT, bool SHADOW>
-__device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
+__device__ __forceinline__ int march(const SceneView &sc, const Lds &lds, const FrameView &fr, V3 (&p)[kPts],
                                       const V3 (&ray)[kPts], V3 (&at)[kPts], const bool (&live)[kPts], float (&to_light)[kPts],
                                       const float (&past_light)[kPts], LaneCounts &cnt, bool (&colourless)[kPts], int iterations,
-                                      bool first_is_shared, uint32_t cw = 0u) {
+                                      bool first_is_shared) {
     bool done[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
@@ -55,7 +56,8 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
     float cap[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) cap[s] = __builtin_inff();
-    for (int it = 0; it < iterations; ++it) {
+    int it = 0;
+    for (; it < iterations; ++it) {
         bool all_done = true;
 #pragma unroll
         for (int s = 0; s < kPts; ++s) all_done = all_done && done[s];
@@ -63,16 +65,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
         float sd[kPts];
         Work work[kPts] = {};
         bool colourless_here[kPts];
-        // cw != 0 (wave-uniform): the ray is marched by a group of cw consecutive lanes, all holding the same point, which
-        // share the evaluation where the scene's evaluator can (lattices: device_core.h, lattice_coop)
-        bool shared_walk = false;
-        if constexpr (Scene::kCoop && kPts == 1 && !COUNT) {
-            if (cw != 0u) {
-                Scene::sd_coop(sc, lds, p, sd, cap, colourless_here, cw);
-                shared_walk = true;
-            }
-        }
-        if (!shared_walk) Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap, colourless_here);
+        Scene::template sd<kPts, COUNT>(sc, lds, p, sd, work, cap, colourless_here);
         probe<COUNT>(kProbeSceneCall, 1u);
         if (COUNT) {
             // the wave sits through this iteration with all of its lanes, whichever of them still march (with one
@@ -100,6 +93,7 @@ __device__ __forceinline__ void march(const SceneView &sc, const Lds &lds, const
             }
         }
     }
+    return it;
 }
 
 // scene::lighting / scene::shadow, scene.cpp:45-62: the shadow ray from a hit to a light, and what lets its march stop
@@ -157,7 +151,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t n_tiles = gridDim.x * ((sh + tile_side - 1u) / tile_side);   // gridDim.x = tiles per row
     if (slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;         // the last grid row's surplus
     const Lds lds = stage_lds(sc);
-    const unsigned long long started = fr.tile_cost ? wall_clock64() : 0ull;
+    const unsigned long long started = (fr.tile_cost || fr.slot_stats) ? wall_clock64() : 0ull;
+    int camera_turns = 0, shadow_turns = 0;
     const uint32_t entry = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
     const uint32_t tile = entry & kTileMask, part = kPts == 1 ? entry >> kTileBits : 0u;
     const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
@@ -167,23 +162,14 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t block = 8u >> split_log2;                                  // the wave's block is block x block samples
     const uint32_t part_side = tile_side >> split_log2;
     const uint32_t part_x = (q & ((1u << split_log2) - 1u)) * part_side, part_y = (q >> split_log2) * part_side;
-    // Wide parts (wave-uniform): where the scene has an evaluator for groups of lanes (Scene::kCoop), a sixteenth's four
-    // samples own a 16-lane row of the wave each -- lanes 16 s .. 16 s + 15 all work for sample s, with the same values --
-    // and the row marches the sample's camera ray as one group, its shadow rays as min(16, lights) groups side by side.
-    constexpr bool kMayBeWide = Scene::kCoop && !COUNT && kPts == 1;
-    const bool wide = kMayBeWide && part >= 5u;
-    const uint32_t unit = wide ? lane >> 4 : lane;                            // the lane's sample, counted within the wave's block
-    const uint32_t col = part_x + wave_x * block + (unit & (block - 1u));
-    const uint32_t row = part_y + wave_y * block + ((unit >> (3u - split_log2)) & (block - 1u));
-    const bool in_part = wide ? (lane & 15u) == 0u : lane < block * block;    // the lane that stores the sample
+    const uint32_t col = part_x + wave_x * block + (lane & (block - 1u));
+    const uint32_t row = part_y + wave_y * block + ((lane >> (3u - split_log2)) & (block - 1u));
+    const bool in_part = lane < block * block;
     // shadow rays spread over the wave's idle lanes (wave-uniform; see above)
     const uint32_t part_lanes = block * block;                                // B: 16 or 4 in a part
-    const bool spread = !wide && RM_SPREAD_SHADOWS != 0 && kPts == 1 && part != 0u && sc.n_lights >= 2u;
-    const uint32_t wide_groups = sc.n_lights < 16u ? (sc.n_lights ? sc.n_lights : 1u) : 16u;
-    const uint32_t groups = wide ? wide_groups : (spread ? (64u / part_lanes < sc.n_lights ? 64u / part_lanes : sc.n_lights) : 1u);   // G
-    const uint32_t rounds = (wide || spread) ? (sc.n_lights + groups - 1u) / groups : sc.n_lights;
-    // wide: lanes per shadow ray, 16 over the next power of two from G (16, 8: a group that shares the walk; less: every lane for itself)
-    const uint32_t ray_lanes_log2 = 4u - (wide_groups > 8u ? 4u : (wide_groups > 4u ? 3u : (wide_groups > 2u ? 2u : wide_groups - 1u)));
+    const bool spread = RM_SPREAD_SHADOWS != 0 && kPts == 1 && part != 0u && sc.n_lights >= 2u;
+    const uint32_t groups = spread ? (64u / part_lanes < sc.n_lights ? 64u / part_lanes : sc.n_lights) : 1u;   // G
+    const uint32_t rounds = spread ? (sc.n_lights + groups - 1u) / groups : sc.n_lights;
     // the lane of the sample whose shadow rays this lane marches, and which of the round's lights it takes: found anew
     // where they are needed (the empty asm keeps the compiler from holding them in registers across the marches)
     const auto lane_now = [] {
@@ -218,9 +204,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     bool stored[kPts], live[kPts], lit[kPts];
 #pragma unroll
     for (int s = 0; s < kPts; ++s) {
-        const bool exists = sx0 + (uint32_t)s < sw && sy < sh;
-        stored[s] = in_part && exists;
-        live[s] = (in_part || wide) && exists && pi < fr.height;   // wide: every lane of the sample's row carries it
+        stored[s] = in_part && sx0 + (uint32_t)s < sw && sy < sh;
+        live[s] = stored[s] && pi < fr.height;
         lit[s] = live[s];
     }
 
@@ -264,8 +249,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                 for (int s = 0; s < kPts; ++s) p[s] = p[s] + ray[s] * sc.camera_sd;
                 iterations--;
             }
-            march<Scene, kPts, COUNT, false>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations, first_is_shared,
-                                             wide ? 16u : 0u);
+            camera_turns = march<Scene, kPts, COUNT, false>(sc, lds, fr, p, ray, at, lit, to_light, past_light, cnt, colourless, iterations,
+                                                            first_is_shared);
         }
         {
 #pragma unroll
@@ -367,13 +352,7 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
             bool marching[kPts];   // the rays of this round
 #pragma unroll
             for (int s = 0; s < kPts; ++s) marching[s] = lit[s];
-            if (wide) {
-                // the lane's group within its sample's row, and that group's light of this round
-                const uint32_t group = (lane_now() & 15u) >> ray_lanes_log2, mine = (r - 1u) * groups + group;
-                const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
-                marching[0] = lit[0] && group < groups && mine < sc.n_lights;
-                shadow_ray(v3(lp.x, lp.y, lp.z), hit[0], normal[0], lift, fr, p[0], ray[0], to_light[0], past_light[0]);
-            } else if (spread) {
+            if (spread) {
                 // the lane's own light of this round (hit, normal and lit are its source sample's by now)
                 const uint32_t group = lane_now() / part_lanes, mine = (r - 1u) * groups + group;
                 const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
@@ -389,21 +368,9 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 #pragma unroll
             for (int s = 0; s < kPts; ++s) at[s] = p[s];
             bool colourless_unused[kPts];
-            march<Scene, kPts, COUNT, true>(sc, lds, fr, p, ray, at, marching, to_light, past_light, cnt, colourless_unused, fr.iterations, false,
-                                            (wide && ray_lanes_log2 >= 3u) ? 1u << ray_lanes_log2 : 0u);
-            if (wide) {
-                const uint32_t now = lane_now(), mine = (r - 1u) * groups + ((now & 15u) >> ray_lanes_log2);
-                const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
-                const float unshadowed = dot3(v3(lp.x, lp.y, lp.z) - p[0], ray[0]) > 0 ? 0.0f : 1.0f;
-                const float towards = dot3(normal[0], ray[0]);
-                // every lane of the row adds the round's contributions in the order of the lights (scene.cpp:55-59)
-                for (uint32_t g = 0; g < groups && (r - 1u) * groups + g < sc.n_lights; ++g) {
-                    const uint32_t from = (now & ~15u) + (g << ray_lanes_log2);
-                    const float open = from_lane(unshadowed, from);
-                    const float term = from_lane(towards, from);
-                    if (open != 0.0f) lighting[0] += term;
-                }
-            } else if (spread) {
+            shadow_turns += march<Scene, kPts, COUNT, true>(sc, lds, fr, p, ray, at, marching, to_light, past_light, cnt, colourless_unused,
+                                                            fr.iterations, false);
+            if (spread) {
                 const uint32_t now = lane_now(), source = now & (part_lanes - 1u), mine = (r - 1u) * groups + now / part_lanes;
                 const Float4 lp = sc.lights[mine < sc.n_lights ? mine : sc.n_lights - 1u];
                 const float unshadowed = dot3(v3(lp.x, lp.y, lp.z) - p[0], ray[0]) > 0 ? 0.0f : 1.0f;
@@ -469,6 +436,22 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 
     // The wave's samples are in LDS (or on their way to memory): it books its arrival and ends, unless it is the
     // workgroup's last, which writes the pixels and the tile's duration.
+    if (fr.slot_stats) {
+        // the wave's longest marches (a lane leaves the loop when its own ray is done), booked by the first wave only
+        int cam = camera_turns, shd = shadow_turns;
+        for (int off = 32; off > 0; off >>= 1) {
+            const int c2 = __shfl_down(cam, off, 64), s2 = __shfl_down(shd, off, 64);
+            cam = c2 > cam ? c2 : cam;
+            shd = s2 > shd ? s2 : shd;
+        }
+        if (threadIdx.x == 0) {
+            uint32_t *out = fr.slot_stats + 4u * slot;
+            out[0] = entry;
+            out[1] = (uint32_t)(wall_clock64() - started);
+            out[2] = (uint32_t)(cam > 65535 ? 65535 : cam) | (uint32_t)(shd > 65535 ? 65535 : shd) << 16;
+            out[3] = (uint32_t)started;
+        }
+    }
     if (fr.tile_cost == nullptr && !fused && !COUNT) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     uint32_t before = 0u;

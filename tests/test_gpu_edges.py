@@ -169,3 +169,31 @@ def test_coloured_sample_with_a_nan_normal(rm, oracle, renderer, lights):
                 assert renderer.render_f32().tobytes() == cpu.tobytes(), f"iterations={iterations} coloured_only={coloured_only}"
         finally:
             renderer.set_shading(True)
+
+
+def test_slot_statistics_cover_every_workgroup(rm, renderer):
+    """rm_set_slot_stats: one record per workgroup of the render, in launch order -- every tile once (whole, or as its 4 or
+    16 parts), durations and march lengths filled in; the frame is the same with the statistics on."""
+    kw = dict(width=160, height=100, kernel=2)
+    renderer.set_params(rm.default_params(**kw))
+    renderer.set_scene(rm.Scene(scene_path("default.txt")))
+    plain = [renderer.render_f32() for _ in range(2)][-1]
+    renderer.set_slot_stats(True)
+    try:
+        frame = renderer.render_f32()
+        st = renderer.slot_stats()
+    finally:
+        renderer.set_slot_stats(False)
+    assert frame.tobytes() == plain.tobytes()
+    side = 8 if renderer.kernel_mode == "compiled" else 16
+    tiles_x = (160 * 2 + (side if side == 8 else 32) - 1) // (side if side == 8 else 32)
+    n_tiles = tiles_x * ((100 * 2 + side - 1) // side)
+    entry, ticks, turns = st[:, 0], st[:, 1], st[:, 2]
+    part = entry >> 27
+    covered = np.zeros(n_tiles)
+    np.add.at(covered, entry & ((1 << 27) - 1), np.where(part == 0, 1.0, np.where(part < 5, 0.25, 1 / 16)))
+    assert np.allclose(covered, 1.0)
+    assert (ticks > 0).all() and ((turns & 0xffff) > 0).all()
+    assert len(st) == n_tiles + renderer.counters()["tile_parts"]
+    renderer.render_f32()
+    assert len(renderer.slot_stats()) == 0          # off again: nothing recorded
