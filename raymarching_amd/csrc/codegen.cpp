@@ -203,10 +203,12 @@ struct Emitter {
             }
             std::snprintf(buf, sizeof buf,
                           "        } while (false);\n"
-                          "        if (state == kLatticeGeneral) lattice_fold_scans<COUNT>(w, g, %uu, p[n], run, evals);\n"
+                          "        if (state == kLatticeGeneral) {\n"
+                          "            if (COUNT) lattice_fold_scans<COUNT>(w, g, %uu, p[n], run, evals);\n"
+                          "            else run = lattice_fold_scans_apart(w, g, %uu, p[n].x, p[n].y, p[n].z, run);\n        }\n"
                           "        %s[n] = run;\n"
                           "        if (COUNT) { work[n].evals += evals; work[n].flops += kFlopsCross * evals; }\n    }\n",
-                          levels, acc(depth).c_str());
+                          levels, levels, acc(depth).c_str());
         }
         s += buf;
     }

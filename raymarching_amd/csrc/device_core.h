@@ -872,6 +872,18 @@ __device__ __forceinline__ void lattice_fold_scans(const uint32_t *w, ConstIndex
     if (COUNT) n_evals += evals;
 }
 
+// lattice_fold_scans as a function of its own.  The generated kernels call it instead of holding its code in line: with
+// the local raise in lattice_level the walk by ranges is left for points deep inside material, where rays do not go,
+// yet its mere presence inside every scene walk cost a tenth of the frame -- the compiler keeps the walk's state live
+// for it and schedules around it (default frame, frames in flight, same GPU: 0.490 ms in line, 0.447 called, 0.436
+// without any such path; the point's whole walk done again at the end of the scene walk by a function of its own, so
+// that the lattice's code holds no call at all: 0.571, the scene's description then lives in memory for that function).
+__device__ __attribute__((noinline)) float lattice_fold_scans_apart(const uint32_t *w, ConstIndex g, uint32_t levels, float px, float py, float pz, float run) {
+    uint32_t evals = 0;
+    lattice_fold_scans<false>(w, g, levels, v3(px, py, pz), run, evals);
+    return run;
+}
+
 // One level of lattice_fold with everything about the level known when the kernel is compiled (the
 // kernels generated for one scene pass the header fields as literals): N = 3^level centres per axis,
 // half-width h, 1 / spacing, the first centre on each axis; `tab` = the level's X table in LDS.
