@@ -662,7 +662,7 @@ int build_grid(rm_context *ctx) {
     RM_HIP(hipStreamSynchronize(ctx->stream));
     // a gigabyte of lists: leave such a scene to the hull walk (the cells' 32-bit offsets are only used below this)
     if (total > grid_entry_limit()) return RM_OK;
-    RM_HIP(ctx->d_grid_entries.reserve(total));
+    RM_HIP(ctx->d_grid_entries.reserve(2u * total));   // (row, lower bound) per entry
     b.entries = ctx->d_grid_entries.ptr;
     RM_HIP(rmdev::launch_fill_grid(b, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));

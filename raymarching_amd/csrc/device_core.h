@@ -533,30 +533,40 @@ __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__res
         outside[n] = !inside;
         if (!inside) continue;
         const uint32_t cell = ((uint32_t)fz * g.dims[1] + (uint32_t)fy) * g.dims[0] + (uint32_t)fx;
+        typedef uint32_t Entry __attribute__((ext_vector_type(2)));   // table row, lower bound over the cell (float bits)
         const Header head = reinterpret_cast<const Header *>(g.cells)[cell];
-        const uint32_t *e = g.entries + head[0];
+        const Entry *e = reinterpret_cast<const Entry *>(g.entries) + head[0];
         const uint32_t n_spheres = head[1], n_boxes = head[2], n_crosses = head[3];
         float a = acc[n];
         const V3 q = p[n];
-        uint32_t i = 0;
-        // (lists are a few rows long: unrolled loops only cost registers here)
+        uint32_t i = 0, done_spheres = 0, done_boxes = 0, done_crosses = 0;
+        // Each class's entries come by rising lower bound: the first one whose bound is not below the running minimum ends
+        // the class (its row's distance, and every later row's, is at least that bound everywhere in the cell).  A
+        // minimum that is not a number ends nothing.  (Lists are a few rows long: unrolled loops only cost registers here.)
         _Pragma("nounroll") for (; i < n_spheres; ++i) {
-            const Float4 ra = pa[e[i]];
+            const Entry en = e[i];
+            if (__uint_as_float(en[1]) >= a) break;
+            const Float4 ra = pa[en[0]];
             const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
             if (!sphere_cannot_change<false, false>(a, d2, ra.w)) a = __builtin_fminf(a, __builtin_sqrtf(d2) - ra.w);
+            done_spheres++;
         }
-        _Pragma("nounroll") for (; i < n_spheres + n_boxes; ++i) {
-            const uint32_t row = e[i];
-            a = __builtin_fminf(a, prim_distance<K_BOX>(pa[row], pb[row], q));
+        _Pragma("nounroll") for (i = n_spheres; i < n_spheres + n_boxes; ++i) {
+            const Entry en = e[i];
+            if (__uint_as_float(en[1]) >= a) break;
+            a = __builtin_fminf(a, prim_distance<K_BOX>(pa[en[0]], pb[en[0]], q));
+            done_boxes++;
         }
-        _Pragma("nounroll") for (; i < n_spheres + n_boxes + n_crosses; ++i) {
-            const uint32_t row = e[i];
-            a = __builtin_fminf(a, prim_distance<K_CROSS>(pa[row], pb[row], q));
+        _Pragma("nounroll") for (i = n_spheres + n_boxes; i < n_spheres + n_boxes + n_crosses; ++i) {
+            const Entry en = e[i];
+            if (__uint_as_float(en[1]) >= a) break;
+            a = __builtin_fminf(a, prim_distance<K_CROSS>(pa[en[0]], pb[en[0]], q));
+            done_crosses++;
         }
         acc[n] = a;
         if (COUNT) {
-            work[n].evals += n_spheres + n_boxes + n_crosses;
-            work[n].flops += kFlopsSphere * n_spheres + kFlopsBox * n_boxes + kFlopsCross * n_crosses;
+            work[n].evals += done_spheres + done_boxes + done_crosses;
+            work[n].flops += kFlopsSphere * done_spheres + kFlopsBox * done_boxes + kFlopsCross * done_crosses;
         }
     }
 }

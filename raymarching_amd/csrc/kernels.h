@@ -39,7 +39,7 @@ struct GridBuild {
     uint32_t *cells;
     float *bound;                 // H per cell
     unsigned long long *total;   // 64 bits: per-cell list sizes of heavily overlapping rows can sum beyond 2^32
-    uint32_t *entries;            // fill pass
+    uint32_t *entries;            // fill pass: 2 words per entry (table row, the row's lower bound over the cell), per class by rising bound
 };
 hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream);
 hipError_t launch_fill_grid(const GridBuild &b, hipStream_t stream);
