@@ -458,7 +458,8 @@ std::string emit_body(const HostProgram &prog, bool track) {
 
 std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting, bool refill) {
     std::string s;
-    s += "#include \"trace_refill.h\"\n\nnamespace rmdev {\n\nstruct CompiledScene {\n";
+    s += "#include \"trace_refill.h\"\n\nnamespace rmdev {\n\n";
+    s += "struct CompiledScene {\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
          "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {\n";
     s += emit_body(prog, false);
@@ -481,8 +482,11 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
                       min_waves, counting ? "rm_trace_refill_counting" : "rm_trace_refill", counting ? "true" : "false");
         s += buf;
     }
-    s += "extern \"C\" __global__ __launch_bounds__(256) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
-         "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n";
+    // (the trace kernel's register budget here too: a function that both kernels call is compiled for the tighter of its callers)
+    std::snprintf(buf, sizeof buf,
+                  "extern \"C\" __global__ __launch_bounds__(256, %d) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
+                  "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n", min_waves);
+    s += buf;
     return s;
 }
 

@@ -886,8 +886,10 @@ __device__ __forceinline__ void lattice_fold_scans(const uint32_t *w, ConstIndex
 // the local raise in lattice_level the walk by ranges is left for points deep inside material, where rays do not go,
 // yet its mere presence inside every scene walk cost a tenth of the frame -- the compiler keeps the walk's state live
 // for it and schedules around it (default frame, frames in flight, same GPU: 0.490 ms in line, 0.447 called, 0.436
-// without any such path; the point's whole walk done again at the end of the scene walk by a function of its own, so
-// that the lattice's code holds no call at all: 0.571, the scene's description then lives in memory for that function).
+// without any such path; the point's whole walk done again behind the scene's walk, so that the lattice's code holds no
+// call at all: 0.571 as a function that takes the scene's description, 0.504 in line; the colour-tracking walk called
+// as well instead of held in line: 0.484).  The price of the call is register traffic: values that live across it are
+// kept in scratch memory at the ends of the kernel's phases, about 60 bytes per sample, once.
 __device__ __attribute__((noinline)) float lattice_fold_scans_apart(const uint32_t *w, ConstIndex g, uint32_t levels, float px, float py, float pz, float run) {
     uint32_t evals = 0;
     lattice_fold_scans<false>(w, g, levels, v3(px, py, pz), run, evals);
