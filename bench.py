@@ -389,6 +389,8 @@ def main():
     if group:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # tiles the scene's exact kernel rendered again behind the optimistic one, in all frames of this process so far
+    exact_tiles = sum(rr.exact_tiles() for rr in rs) if a.kernel_mode == "compiled" else 0
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
     if timed_kernel_ms:
         kernel_ms = overlapped_ms = sum(timed_kernel_ms) / len(timed_kernel_ms)   # one frame in flight: the timed frames themselves
@@ -625,6 +627,7 @@ def main():
             "frame_alone_device_ms": host["frame_alone_ms"] if host else None,
             "value_every_ray_marched": all_marched["value"] if all_marched else None,
             "host_issue_ms_per_frame": round(host_issue_ms, 4),
+            "tiles_rendered_again_by_the_exact_kernel": exact_tiles,
             "mrays_cast_per_s": round(total_rays * a.steps / elapsed / 1e6, 3),
             "every_ray_marched": all_marched,
             "host_image": host,

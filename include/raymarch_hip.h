@@ -202,6 +202,8 @@ int rm_set_stream(rm_context *ctx, void *hip_stream);
  * (no hipMalloc / hipFree, no allocating library routine): what the kernels need beyond the caller's buffers --
  * the SSAA sample image that the trace kernel leaves for the resolve kernel, 8 bytes per sample, wherever the
  * trace kernel does not write the pixels itself -- lives in a static device array of RM_STATIC_SCRATCH_BYTES
+ * (plus 16 MiB behind it: one word per tile, up to 4 194 304 tiles, through which a scene's own kernel asks for
+ * tiles to be rendered again by its exact kernel; renders of more tiles are refused)
  * that every GPU the library runs on holds from the first rm_create on it until the process ends.
  *   - A render whose sample image (band_count * band_rows * kernel rows of width * kernel samples) exceeds
  *     the array is refused with RM_ERR_INVALID (render fewer rows per call) -- unless the scene has kernels of
@@ -344,6 +346,16 @@ int rm_set_kernel_cache_dir(const char *directory);
  */
 int rm_set_slot_stats(rm_context *ctx, int enabled);
 int rm_get_slot_stats(rm_context *ctx, uint32_t *words, size_t capacity_slots, size_t *n_slots);
+
+/*
+ * Diagnostic (no counterpart in the reference): the kernel generated for a scene with recognised lattices decides a
+ * point's distance to a lattice from the crosses round the nearest centres and, where that is not enough (deep inside
+ * material, where rays as good as never go), marks the point's tile; a second kernel of the scene, launched behind it
+ * in every render, renders the marked tiles again with the full walk.  *tiles: how many tiles that second kernel has
+ * rendered in this context since the last rm_set_scene (0 for frames that never needed it).  Waits for the context's
+ * stream.
+ */
+int rm_get_exact_tiles(rm_context *ctx, uint64_t *tiles);
 
 /* Enable (1) / disable (0) per-ray work counting in subsequent renders. */
 int rm_set_counting(rm_context *ctx, int enabled);

@@ -25,8 +25,11 @@
 #include "program.h"
 #include "scene.h"
 
-// The static scratch of rm_enqueue_device_static (see find_static_scratch below).
-static __device__ __align__(256) unsigned char scratch[RM_STATIC_SCRATCH_BYTES];
+// The static scratch of rm_enqueue_device_static (see find_static_scratch below): RM_STATIC_SCRATCH_BYTES for the SSAA sample
+// image, then a word per tile (up to kStaticFlagTiles of them) for the tiles that the scene's optimistic kernel asks its exact
+// kernel to render again (FrameView::tile_flags; zero when the code object is loaded, and the kernels leave them zero).
+constexpr size_t kStaticFlagTiles = 4u << 20;
+static __device__ __align__(256) unsigned char scratch[RM_STATIC_SCRATCH_BYTES + kStaticFlagTiles * sizeof(uint32_t)];
 
 int rm_write_png_file(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);   // png.cpp
 
@@ -149,6 +152,7 @@ struct rm_context {
     DeviceArray<unsigned char> d_frame_rgba8;
     DeviceArray<rmdev::WorkCounters> d_counters;
     DeviceArray<float> d_points, d_sd, d_camera;
+    DeviceArray<uint32_t> d_tile_flags;   // FrameView::tile_flags: a word per tile, zero between launches
     DeviceArray<uint32_t> d_slot_stats;   // rm_set_slot_stats: four words per workgroup slot of the last render
     bool slot_stats = false;
     size_t slot_stats_slots = 0;
@@ -388,6 +392,16 @@ int preload_tile_order(rm_context *ctx) {
     return RM_OK;
 }
 
+// The words through which a scene's optimistic kernel asks for tiles to be rendered again (FrameView::tile_flags): at least
+// `tiles` of them, zero.  The kernels leave them zero, so they are cleared only when the buffer is new.
+int ensure_tile_flags(rm_context *ctx, size_t tiles) {
+    if (ctx->d_tile_flags.ptr && ctx->d_tile_flags.capacity >= tiles) return RM_OK;
+    RM_HIP(hipStreamSynchronize(ctx->stream));   // no launch may still be using the old words
+    RM_HIP(ctx->d_tile_flags.reserve(tiles));
+    RM_HIP(hipMemsetAsync(ctx->d_tile_flags.ptr, 0, ctx->d_tile_flags.capacity * sizeof(uint32_t), ctx->stream));
+    return RM_OK;
+}
+
 // static_samples: the device's static scratch (rm_enqueue_device_static) -- the call then allocates nothing: the sample
 // image goes there, tiles are never timed, and a configuration that would need a buffer the context does not hold is refused.
 int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure,
@@ -475,9 +489,23 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
                                          ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
+    // the scene's own kernel walks optimistically; its exact kernel follows it over the tiles it flags (rarely any)
+    const bool optimistic = compiled && !ctx->counting && !refill && ctx->module.trace_exact != nullptr;
+    if (optimistic && static_samples) {
+        // the call that allocates nothing: the words live behind the sample image in the static scratch
+        if (pend.n_tiles > kStaticFlagTiles)
+            return fail(RM_ERR_INVALID, "rm_enqueue_device_static: this render has " + std::to_string(pend.n_tiles) + " tiles, the static buffer holds the flags of " +
+                                            std::to_string(kStaticFlagTiles) + " (render fewer rows per call, or use rm_enqueue_device)");
+        fr.tile_flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(static_scratch(ctx->device)) + kStaticScratchBytes);
+    } else if (optimistic) {
+        if (int rc = ensure_tile_flags(ctx, pend.n_tiles)) return rc;
+        fr.tile_flags = ctx->d_tile_flags.ptr;
+    }
+    if (optimistic && ctx->d_warm.ptr) fr.exact_count = reinterpret_cast<uint32_t *>(ctx->d_warm.ptr + 512);
     RM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (compiled) RM_HIP(rmdev::launch_trace_module(ctx->counting ? ctx->counting_module : ctx->module, ctx->scene, fr, n_side, samples, d_cnt, ctx->stream));
     else RM_HIP(rmdev::launch_trace(ctx->scene, fr, wide_runs, samples, d_cnt, ctx->stream));
+    if (optimistic) RM_HIP(rmdev::launch_trace_exact_module(ctx->module, ctx->scene, fr, n_side, samples, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     if (!fused) RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, samples, d_f32, d_rgba8, ctx->stream));
     RM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -730,6 +758,7 @@ int rm_destroy(rm_context *ctx) {
     ctx->d_grid_cells.release(); ctx->d_grid_entries.release(); ctx->d_grid_total.release(); ctx->d_grid_bound.release();
     ctx->d_warm.release();
     ctx->d_slot_stats.release();
+    ctx->d_tile_flags.release();
     ctx->d_sd.release(); ctx->d_prim.release(); ctx->d_lattice.release(); ctx->d_row_prim.release(); ctx->d_camera.release();
     for (int i = 0; i < 3; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -765,6 +794,7 @@ int rm_reserve(rm_context *ctx) {
     if (!writes_pixels) RM_HIP(ctx->d_samples.reserve(samples));
     const size_t tiles = ((size_t)p.width * p.kernel + 7u) / 8u * (((size_t)p.height * p.kernel + 7u) / 8u);
     RM_HIP(ctx->d_tile_cost.reserve(tiles));
+    if (int rc = ensure_tile_flags(ctx, tiles)) return rc;
     RM_HIP(ctx->d_tile_order.reserve(tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
     RM_HIP(ctx->h_tiles.reserve(tiles + 15u * kSixteenthTiles + 3u * kQuarterTiles));
     // first use by the GPU is what makes fresh device memory resident (milliseconds for a frame's worth): now, not in the first frame
@@ -900,9 +930,12 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         fr.surface_eps = fr.offset_eps = 1e-3f;
         fr.band_rows = fr.band_stride = fr.band_count = 1u;
         // into a buffer of the context's own: the GPU's static scratch may hold another context's frame in flight
-        RM_HIP(ctx->d_warm.reserve(512));
+        RM_HIP(ctx->d_warm.reserve(1024));   // (the word at 512 counts the tiles the exact kernel renders: rm_get_exact_tiles)
         unsigned char *const spare = ctx->d_warm.ptr;
+        RM_HIP(hipMemsetAsync(spare, 0, 1024, ctx->stream));
+        fr.tile_flags = reinterpret_cast<uint32_t *>(spare + 384);   // (zero: the exact kernel finds nothing to do, but has been launched once)
         RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
+        RM_HIP(rmdev::launch_trace_exact_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), ctx->stream));
         RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
         RM_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -1163,6 +1196,18 @@ int rm_get_slot_stats(rm_context *ctx, uint32_t *words, size_t capacity_slots, s
         if (ctx->slot_stats_slots)
             RM_HIP(hipMemcpy(words, ctx->d_slot_stats.ptr, 4u * ctx->slot_stats_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
+    return RM_OK;
+}
+
+int rm_get_exact_tiles(rm_context *ctx, uint64_t *tiles) {
+    if (!ctx || !tiles) return fail(RM_ERR_INVALID, "rm_get_exact_tiles: null argument");
+    *tiles = 0;
+    if (!ctx->d_warm.ptr) return RM_OK;
+    RM_HIP(hipSetDevice(ctx->device));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t word = 0;
+    RM_HIP(hipMemcpy(&word, ctx->d_warm.ptr + 512, sizeof(word), hipMemcpyDeviceToHost));
+    *tiles = word;
     return RM_OK;
 }
 

@@ -204,11 +204,12 @@ struct Emitter {
             std::snprintf(buf, sizeof buf,
                           "        } while (false);\n"
                           "        if (state == kLatticeGeneral) {\n"
-                          "            if (COUNT) lattice_fold_scans<COUNT>(w, g, %uu, p[n], run, evals);\n"
-                          "            else run = lattice_fold_scans_apart(w, g, %uu, p[n].x, p[n].y, p[n].z, run);\n        }\n"
+                          "            if (COUNT || EXACT) lattice_fold_scans<COUNT>(w, g, %uu, p[n], run, evals);\n"
+                          "            // an optimistic walk goes on with the lower bound it has and asks for the tile to be rendered again\n"
+                          "            else *exact_wanted_word() = 1u;\n        }\n"
                           "        %s[n] = run;\n"
                           "        if (COUNT) { work[n].evals += evals; work[n].flops += kFlopsCross * evals; }\n    }\n",
-                          levels, levels, acc(depth).c_str());
+                          levels, acc(depth).c_str());
         }
         s += buf;
     }
@@ -459,7 +460,8 @@ std::string emit_body(const HostProgram &prog, bool track) {
 std::string generate_scene_source(const HostProgram &prog, int points_per_lane, int min_waves, bool counting, bool refill) {
     std::string s;
     s += "#include \"trace_refill.h\"\n\nnamespace rmdev {\n\n";
-    s += "struct CompiledScene {\n";
+    // EXACT = false: the optimistic walk of the frame's kernel (see FrameView::tile_flags); true: every walk decided on the spot
+    s += "template <bool EXACT>\nstruct CompiledSceneT {\nstatic constexpr bool kOptimistic = !EXACT;\n";
     s += "template <int NP, bool COUNT>\nstatic __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP],\n"
          "                                          float (&out_sd)[NP], Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {\n";
     s += emit_body(prog, false);
@@ -472,20 +474,26 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
     char buf[1024];
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(576, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
-                  "        WorkCounters *counters) {\n    trace_body<CompiledScene, %d, %s>(sc, fr, samples, counters);\n}\n\n",
-                  min_waves, counting ? "rm_trace_counting" : "rm_trace", points_per_lane, counting ? "true" : "false");
+                  "        WorkCounters *counters) {\n    trace_body<CompiledSceneT<%s>, %d, %s>(sc, fr, samples, counters);\n}\n\n",
+                  min_waves, counting ? "rm_trace_counting" : "rm_trace", counting ? "true" : "false", points_per_lane, counting ? "true" : "false");
     s += buf;
+    if (!counting) {
+        // the pass behind rm_trace over the tiles it flagged (trace_kernel.h: trace_exact_body); same workgroup shapes
+        std::snprintf(buf, sizeof buf,
+                      "extern \"C\" __global__ __launch_bounds__(576, %d) void rm_trace_exact(const SceneView sc, const FrameView fr, Sample *samples) {\n"
+                      "    trace_exact_body<CompiledSceneT<true>, %d>(sc, fr, samples);\n}\n\n", min_waves, points_per_lane);
+        s += buf;
+    }
     if (refill) {
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(64, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
-                      "        WorkCounters *counters) {\n    trace_refill_body<CompiledScene, %s>(sc, fr, samples, counters);\n}\n\n",
+                      "        WorkCounters *counters) {\n    trace_refill_body<CompiledSceneT<true>, %s>(sc, fr, samples, counters);\n}\n\n",
                       min_waves, counting ? "rm_trace_refill_counting" : "rm_trace_refill", counting ? "true" : "false");
         s += buf;
     }
-    // (the trace kernel's register budget here too: a function that both kernels call is compiled for the tighter of its callers)
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(256, %d) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
-                  "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledScene>(sc, xyz, n, sd, prim, sd_march);\n}\n", min_waves);
+                  "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledSceneT<true>>(sc, xyz, n, sd, prim, sd_march);\n}\n", min_waves);
     s += buf;
     return s;
 }

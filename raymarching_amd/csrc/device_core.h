@@ -882,18 +882,15 @@ __device__ __forceinline__ void lattice_fold_scans(const uint32_t *w, ConstIndex
     if (COUNT) n_evals += evals;
 }
 
-// lattice_fold_scans as a function of its own.  The generated kernels call it instead of holding its code in line: with
-// the local raise in lattice_level the walk by ranges is left for points deep inside material, where rays do not go,
-// yet its mere presence inside every scene walk cost a tenth of the frame -- the compiler keeps the walk's state live
-// for it and schedules around it (default frame, frames in flight, same GPU: 0.490 ms in line, 0.447 called, 0.436
-// without any such path; the point's whole walk done again behind the scene's walk, so that the lattice's code holds no
-// call at all: 0.571 as a function that takes the scene's description, 0.504 in line; the colour-tracking walk called
-// as well instead of held in line: 0.484).  The price of the call is register traffic: values that live across it are
-// kept in scratch memory at the ends of the kernel's phases, about 60 bytes per sample, once.
-__device__ __attribute__((noinline)) float lattice_fold_scans_apart(const uint32_t *w, ConstIndex g, uint32_t levels, float px, float py, float pz, float run) {
-    uint32_t evals = 0;
-    lattice_fold_scans<false>(w, g, levels, v3(px, py, pz), run, evals);
-    return run;
+// One LDS word per workgroup: set by an optimistic scene walk that met a point it could not decide (trace_kernel.h books it
+// into FrameView::tile_flags).  Why the exact walk is not simply part of every kernel: its mere presence inside the scene
+// walk cost a tenth of the frame -- the compiler keeps the walk's state live for it and schedules around it.  Default
+// frame, frames in flight, same GPU: 0.490 ms with lattice_fold_scans in line at the lattice, 0.447 called there as a
+// function (and 60 bytes of register spills per sample around the call, 0.45 GB per frame), 0.436 without it; the point's
+// whole walk repeated behind the scene's walk: 0.504 in line, 0.571 as a function that takes the scene's description.
+__device__ __forceinline__ uint32_t *exact_wanted_word() {
+    __shared__ uint32_t word;
+    return &word;
 }
 
 // One level of lattice_fold with everything about the level known when the kernel is compiled (the

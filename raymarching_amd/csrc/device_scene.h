@@ -201,6 +201,13 @@ struct FrameView {
     // the lighting is zero either way) and shadow rays stop once past their light; zero: every sample and
     // ray does the reference's full work, which is what work counts that are compared with the reference's need.
     uint32_t skip_unlit;
+    // One word per tile of the launch's sample image, zero between launches (null: none).  The kernels generated for a scene
+    // are optimistic: where a point's lattice walk cannot be decided from the nearest centres (deep inside material,
+    // where rays as good as never go) they go on with a lower bound and set the tile's word; the scene's exact kernel,
+    // launched behind them, renders the set tiles again -- every walk exact -- and clears their words.
+    uint32_t *tile_flags;
+    // Null, or a word the exact kernel adds one to for every tile it renders again.
+    uint32_t *exact_count;
     // Diagnostic (null: off): four words per workgroup slot of the launch -- its tile_order entry, its duration in 10 ns
     // ticks, the iterations its wave spent in the camera march (low 16 bits) and in its shadow marches (high 16 bits; the
     // loops' trip counts: the wave's longest ray each time), and the clock at its start.  Tells which workgroups a frame

@@ -20,6 +20,7 @@ namespace rmdev {
 // accumulator" needs no case of its own; an empty list keeps +inf / no colour.
 
 struct InterpretedScene {
+    static constexpr bool kOptimistic = false;   // every walk of the record walker is exact
     template <int NP, bool COUNT>
     static __device__ __forceinline__ void sd(const SceneView &sc, const Lds &lds, const V3 (&p)[NP], float (&out_sd)[NP],
                                              Work (&work)[NP], const float (&cap)[NP], bool (&colourless)[NP]) {

@@ -29,7 +29,7 @@ namespace {
 
 using CodeObject = std::shared_ptr<const std::vector<char>>;
 std::mutex g_cache_lock;
-std::unordered_map<std::string, CodeObject> g_cache;   // source text -> gfx950 code object
+std::unordered_map<std::string, CodeObject> g_cache;   // source text and $RM_JIT_EXTRA -> gfx950 code object
 std::string g_cache_dir;                                // second level on disk ("" = none)
 bool g_cache_dir_chosen = false;                        // set_kernel_cache_dir was called, or the default was looked up
 
@@ -282,9 +282,11 @@ bool check_scene_source(const std::string &source, std::string &log) {
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
     out.unload();
     CodeObject code;
+    std::string memory_key = source;   // (the embedded headers cannot change within a process; $RM_JIT_EXTRA can)
+    for (const std::string &o : extra_options()) memory_key += "\n//@option " + o;
     {
         std::lock_guard<std::mutex> hold(g_cache_lock);
-        auto it = g_cache.find(source);
+        auto it = g_cache.find(memory_key);
         if (it != g_cache.end()) code = it->second;
     }
     double seconds = 0.0;
@@ -299,7 +301,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> hold(g_cache_lock);
         if (g_cache.size() >= 256) g_cache.clear();   // a caller that streams ever-new scenes should not grow without bound
-        g_cache.emplace(source, code);
+        g_cache.emplace(memory_key, code);
     }
     hipError_t e = hipModuleLoadData(&out.module, code->data());
     if (e != hipSuccess) {
@@ -315,6 +317,14 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         e = hipModuleGetFunction(sym.fn, out.module, sym.name);
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(") + sym.name + "): " + hipGetErrorString(e);
+            out.unload();
+            return false;
+        }
+    }
+    if (source.find("rm_trace_exact") != std::string::npos) {
+        e = hipModuleGetFunction(&out.trace_exact, out.module, "rm_trace_exact");
+        if (e != hipSuccess) {
+            log = std::string("hipModuleGetFunction(rm_trace_exact): ") + hipGetErrorString(e);
             out.unload();
             return false;
         }
@@ -356,6 +366,26 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
     const uint32_t lds = (sc.lattice_words + (writes_pixels ? 3u * side * side : 0u)) * 4u;
     return hipModuleLaunchKernel(m.trace, tiles_x, (sh + side - 1u) / side + extra_rows, 1, 64u * waves_per_side * waves_per_side, 1, 1,
                                  lds, stream, args, nullptr);
+}
+
+hipError_t launch_trace_exact_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
+                                     hipStream_t stream) {
+    const uint32_t sw = fr.width * fr.kernel;
+    const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
+    if (sw == 0 || sh == 0 || !m.trace_exact || !fr.tile_flags) return hipSuccess;
+    const uint32_t side = 8u * waves_per_side, pts = m.points_per_lane;
+    const size_t n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
+    SceneView sc_arg = sc;
+    FrameView fr_arg = fr;
+    fr_arg.tile_order = nullptr;   // whole tiles in natural order, nothing timed
+    fr_arg.extra_slots = 0u;
+    fr_arg.tile_cost = nullptr;
+    fr_arg.slot_stats = nullptr;
+    void *args[] = { &sc_arg, &fr_arg, &samples };
+    const bool writes_pixels = fr.pixels_f32 || fr.pixels_rgba8;
+    const uint32_t lds = (sc.lattice_words + (writes_pixels ? 3u * side * side : 0u)) * 4u;
+    return hipModuleLaunchKernel(m.trace_exact, (uint32_t)((n_tiles + 63u) / 64u), 1, 1, 64u * waves_per_side * waves_per_side, 1, 1, lds, stream,
+                                 args, nullptr);
 }
 
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,

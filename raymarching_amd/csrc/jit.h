@@ -21,6 +21,7 @@ extern const unsigned kEmbeddedHeaderCount;
 struct SceneModule {
     hipModule_t module = nullptr;
     hipFunction_t trace = nullptr;
+    hipFunction_t trace_exact = nullptr;    // the pass over the tiles `trace` flagged (null in work-counting modules: their walks are exact)
     hipFunction_t trace_refill = nullptr;   // null unless the source holds it
     hipFunction_t eval_sdf = nullptr;
     uint32_t points_per_lane = 0;   // of `trace`
@@ -51,6 +52,9 @@ bool check_scene_source(const std::string &source, std::string &log);
 // LDS: the lattice tables and, when the kernel writes pixels (fr.pixels_*), the tile's sample colours.
 hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
                                WorkCounters *counters, hipStream_t stream);
+// The exact pass behind launch_trace_module over the same frame: one workgroup of the frame's shape per 64 tiles.
+hipError_t launch_trace_exact_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
+                                     hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                                   uint32_t *prim, float *sd_march, hipStream_t stream);
 

@@ -131,11 +131,19 @@ __device__ __forceinline__ void shadow_ray(V3 light, V3 hit, V3 normal, float li
 // sample s to light `first + g` of the round, all G at once, and the sample's own lane then adds the contributions
 // up in the order of the lights, as the reference's loop does.  The serial path of a sample goes from 1 + L marches
 // to 1 + ceil(L / G); every ray is the same ray, so the frame and the work counters do not change.
+//
+// forced_tile (kNoForcedTile: none): the workgroup renders that whole tile, whatever its place in the grid (the exact
+// kernel's second pass over flagged tiles, trace_exact_body).
+constexpr uint32_t kNoForcedTile = 0xffffffffu;
+
 template <class Scene, int kPts, bool COUNT>
 __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples,
-                                           WorkCounters *__restrict__ counters) {
+                                           WorkCounters *__restrict__ counters, uint32_t forced_tile = kNoForcedTile) {
     __shared__ uint32_t arrived;
-    if (threadIdx.x == 0) arrived = 0u;
+    if (threadIdx.x == 0) {
+        arrived = 0u;
+        if (Scene::kOptimistic) *exact_wanted_word() = 0u;
+    }
     if (COUNT) {
         if (threadIdx.x < 16) probe_words()[threadIdx.x] = 0;
     }
@@ -147,15 +155,16 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     const uint32_t k = fr.kernel;
     const uint32_t sw = fr.width * k;
     const uint32_t sh = fr.band_count * fr.band_rows * k;
+    const uint32_t tiles_x = (sw + tile_side * (uint32_t)kPts - 1u) / (tile_side * (uint32_t)kPts);   // = gridDim.x of a frame's launch
     const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t n_tiles = gridDim.x * ((sh + tile_side - 1u) / tile_side);   // gridDim.x = tiles per row
-    if (slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;         // the last grid row's surplus
+    const uint32_t n_tiles = tiles_x * ((sh + tile_side - 1u) / tile_side);
+    if (forced_tile == kNoForcedTile && slot >= n_tiles + (fr.tile_order ? fr.extra_slots : 0u)) return;   // the last grid row's surplus
     const Lds lds = stage_lds(sc);
     const unsigned long long started = (fr.tile_cost || fr.slot_stats) ? wall_clock64() : 0ull;
     int camera_turns = 0, shadow_turns = 0;
-    const uint32_t entry = fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot;
+    const uint32_t entry = forced_tile != kNoForcedTile ? forced_tile : (fr.tile_order ? ((ConstIndex)fr.tile_order)[slot] : slot);
     const uint32_t tile = entry & kTileMask, part = kPts == 1 ? entry >> kTileBits : 0u;
-    const uint32_t tile_y = tile / gridDim.x, tile_x = tile - tile_y * gridDim.x;
+    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     // the part's place in the tile, the wave's block in the part, the lane's sample in the block (all in samples)
     const uint32_t split_log2 = part == 0u ? 0u : (part < 5u ? 1u : 2u);      // parts per tile side: 1, 2 or 4
     const uint32_t q = part == 0u ? 0u : (part < 5u ? part - 1u : part - 5u);
@@ -436,6 +445,15 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
 
     // The wave's samples are in LDS (or on their way to memory): it books its arrival and ends, unless it is the
     // workgroup's last, which writes the pixels and the tile's duration.
+    if (Scene::kOptimistic) {
+        // some walk of this workgroup went on with a lower bound (every wave that finds the word set says so: the wave that
+        // set it is among them): the exact kernel renders the tile again
+#ifdef RM_FLAG_EVERY_TILE   // (tests: the exact kernel renders the whole frame over the optimistic one's)
+        if (fr.tile_flags && lane == 0u) fr.tile_flags[tile] = 1u;
+#else
+        if (fr.tile_flags && *exact_wanted_word() != 0u && lane == 0u) fr.tile_flags[tile] = 1u;
+#endif
+    }
     if (fr.slot_stats) {
         // the wave's longest marches (a lane leaves the loop when its own ray is done), booked by the first wave only
         int cam = camera_turns, shd = shadow_turns;
@@ -481,6 +499,36 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     if (fr.tile_cost && lane == 0u) fr.tile_cost[tile] = (uint32_t)(wall_clock64() - started);
     if (COUNT) {
         if (lane < 16u && probe_words()[lane]) atomicAdd(&counters->probe[lane], probe_words()[lane]);
+    }
+}
+
+// The exact kernel's pass behind an optimistic launch: workgroup b looks at tiles 64 b .. 64 b + 63 of the launch's sample
+// image and renders those whose word in FrameView::tile_flags is set, whole and in natural order, with a scene whose every
+// walk is exact; the words are cleared on the way.  Launched with the frame's workgroup shape; almost always every
+// workgroup finds nothing and ends.
+template <class Scene, int kPts>
+__device__ __forceinline__ void trace_exact_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples) {
+    __shared__ unsigned long long flagged;
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t tile_side = 8u * (n_waves == 1u ? 1u : (n_waves == 4u ? 2u : 3u));
+    const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
+    const uint32_t n_tiles = ((sw + tile_side * (uint32_t)kPts - 1u) / (tile_side * (uint32_t)kPts)) * ((sh + tile_side - 1u) / tile_side);
+    const uint32_t first = blockIdx.x * 64u;
+    if (threadIdx.x < 64u) {
+        const uint32_t t = first + threadIdx.x;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(t < n_tiles && fr.tile_flags[t] != 0u);
+        if (threadIdx.x == 0u) flagged = mask;
+    }
+    __syncthreads();
+    unsigned long long todo = flagged;   // the same for every wave
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const uint32_t tile = first + (uint32_t)__builtin_ctzll(todo);
+        if (threadIdx.x == 0u) {
+            fr.tile_flags[tile] = 0u;
+            if (fr.exact_count) atomicAdd(fr.exact_count, 1u);
+        }
+        trace_body<Scene, kPts, false>(sc, fr, samples, nullptr, tile);
+        __syncthreads();   // the tile's LDS (tables, sample colours, counters) is free for the next one
     }
 }
 

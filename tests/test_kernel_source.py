@@ -12,6 +12,7 @@ from conftest import scene_path
 def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
     src = rm.kernel_source(rm.Scene(scene_path(name)), lattice=lattice)
     assert 'extern "C" __global__' in src and "rm_trace" in src and "rm_eval_sdf" in src
+    assert "rm_trace_exact" in src and "trace_body<CompiledSceneT<false>, 1, false>" in src   # the optimistic kernel and its exact pass
     assert ("lattice_level<" in src) == (lattice and name != "synthetic1024.txt")
     assert ("fold_run_clustered<" in src) == (name == "synthetic1024.txt")
     rm.kernel_source_compiles(src)
@@ -20,7 +21,7 @@ def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
 def test_counting_variant_and_compile_errors(rm):
     scene = rm.Scene(scene_path("menger2.txt"))
     counted = rm.kernel_source(scene, counting=True)
-    assert "trace_body<CompiledScene, 1, true>" in counted
+    assert "trace_body<CompiledSceneT<true>, 1, true>" in counted and "rm_trace_exact" not in counted
     rm.kernel_source_compiles(counted)
     with pytest.raises(rm.RaymarchError) as e:
         rm.kernel_source_compiles(counted.replace("single_sd<", "no_such_function<", 1))
