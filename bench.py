@@ -225,16 +225,13 @@ def main():
     # ---- contexts: one per frame in flight, each on its own stream (frames are independent; the tail of one
     # frame's long-running tiles overlaps the start of the next frame, and the gather of frame i overlaps the
     # render of frame i + 1)
-    # The smaller a rank's share, the more frames it takes to hide one frame's longest tiles (rank 0's eighth of the
-    # default frame through a one-rank gather, 400 timed frames: 0.116 ms per frame with 8 in flight, 0.100 with 16;
-    # with 20 timed frames the count makes no difference).
-    split = max(world, a.emulate_share)
-    F = a.frames_in_flight if a.frames_in_flight > 0 else (4 if split < 8 else 16)
-    # frames per collective: queueing a gather costs the host ~0.03 ms, and frames gathered together wait for each other.
-    # One per frame up to four ranks; from eight on a rank's share of a default frame takes 0.065 ms to render, the host
-    # is the slower side, and two frames share a collective (rank 0's eighth through a one-rank gather, ms per frame:
-    # 20 timed frames 0.127 against 0.150, 400 timed frames 0.104 against 0.100)
-    G = a.frames_per_gather if a.frames_per_gather > 0 else (1 if split < 8 else 2)
+    # Four frames in flight hide one frame's longest tiles at every share size measured (rank 0's eighth of the default
+    # frame through a one-rank gather, 400 timed frames, ms per frame: 2 in flight 0.110, 3 0.092, 4 0.081, 8 0.093,
+    # 16 0.089; tools/gather_sweep.sh).
+    F = a.frames_in_flight if a.frames_in_flight > 0 else 4
+    # frames per collective: one.  Frames gathered together wait for each other (the same share, 16 in flight: one frame
+    # per gather 0.090 ms per frame, two 0.092, four 0.100, eight 0.103).
+    G = a.frames_per_gather if a.frames_per_gather > 0 else 1
     if F % G:
         raise SystemExit("--frames-in-flight must be a multiple of --frames-per-gather")
     if a.balance:
