@@ -675,7 +675,7 @@ int build_grid(rm_context *ctx) {
     }
     b.cell = (float)cell;
     const auto t0 = std::chrono::steady_clock::now();
-    RM_HIP(ctx->d_grid_cells.reserve(n_cells * 4));
+    RM_HIP(ctx->d_grid_cells.reserve(n_cells * 2));
     RM_HIP(ctx->d_grid_bound.reserve(n_cells));
     RM_HIP(ctx->d_grid_total.reserve(1));
     b.pa = ctx->d_pa.ptr;
@@ -690,7 +690,7 @@ int build_grid(rm_context *ctx) {
     RM_HIP(hipStreamSynchronize(ctx->stream));
     // a gigabyte of lists: leave such a scene to the hull walk (the cells' 32-bit offsets are only used below this)
     if (total > grid_entry_limit()) return RM_OK;
-    RM_HIP(ctx->d_grid_entries.reserve(2u * total));   // (row, lower bound) per entry
+    RM_HIP(ctx->d_grid_entries.reserve(2u * total + 2u));   // (row and class, lower bound) per entry
     b.entries = ctx->d_grid_entries.ptr;
     RM_HIP(rmdev::launch_fill_grid(b, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));

@@ -291,7 +291,7 @@ struct Emitter {
         // The root's clustered runs that the cell grid covers (program.cpp: grid_runs) are evaluated through the grid; the
         // hull walk is what lanes outside the grid's box fall back to.
         std::vector<const Item *> gridded;
-        if (!track && depth == 0 && !prog.grid_runs.empty()) {
+        if (depth == 0 && !prog.grid_runs.empty()) {
             std::vector<const Item *> others;
             for (const Item *it : order) {
                 const Rec &r = prog.recs[it->rec];
@@ -376,8 +376,10 @@ struct Emitter {
         }
         book();
         if (!gridded.empty()) {
-            s += "    if (sc.grid.cells) {\n    bool outside[NP];\n    bool any_outside = false;\n"
-                 "    grid_fold<NP, COUNT>(sc.grid, sc.pa, sc.pb, p, a0, outside, work);\n"
+            s += "    if (sc.grid.cells) {\n    bool outside[NP];\n    bool any_outside = false;\n";
+            s += track ? "    grid_surface<NP>(sc.grid, sc.pa, sc.pb, sc.row_prim, p, a0, q0, outside);\n"
+                       : "    grid_fold<NP, COUNT>(sc.grid, sc.pa, sc.pb, p, a0, outside, work);\n";
+            s += 
                  "    _Pragma(\"unroll\") for (int n = 0; n < NP; ++n) any_outside = any_outside || outside[n];\n"
                  "    if (__builtin_amdgcn_ballot_w64(any_outside) != 0) {\n    keep_in_branch();\n    if (any_outside) {\n";
             for (const Item *it : gridded) leaf(prog.recs[it->rec], depth);
@@ -477,8 +479,9 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
                   "        WorkCounters *counters) {\n    trace_body<CompiledSceneT<%s>, %d, %s>(sc, fr, samples, counters);\n}\n\n",
                   min_waves, counting ? "rm_trace_counting" : "rm_trace", counting ? "true" : "false", points_per_lane, counting ? "true" : "false");
     s += buf;
-    if (!counting) {
-        // the pass behind rm_trace over the tiles it flagged (trace_kernel.h: trace_exact_body); same workgroup shapes
+    if (!counting && s.find("exact_wanted_word") != std::string::npos) {
+        // the pass behind rm_trace over the tiles it flagged (trace_kernel.h: trace_exact_body); same workgroup shapes.
+        // Only scenes with a lattice can flag a tile: the others get no such kernel, and their renders no such launch.
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(576, %d) void rm_trace_exact(const SceneView sc, const FrameView fr, Sample *samples) {\n"
                       "    trace_exact_body<CompiledSceneT<true>, %d>(sc, fr, samples);\n}\n\n", min_waves, points_per_lane);

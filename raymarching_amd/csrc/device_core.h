@@ -522,52 +522,92 @@ __device__ __forceinline__ void fold_run_clustered(ConstRows pa, ConstRows pb, u
 // min(acc, v) over the rows listed for the cell that holds p -- every row that can be the smallest there -- with the
 // plain formulas.  Each lane walks its own cell's list (its own trip count, its own gathers).  outside[n]: p[n] is not in
 // the grid's box (or not a number); its accumulator is left as it is, for the hull walk to finish.
+__device__ __forceinline__ bool grid_cell_of(const GridView &g, const V3 p, uint32_t &cell) {
+    const float fx = (p.x - g.origin[0]) * g.inv_cell, fy = (p.y - g.origin[1]) * g.inv_cell, fz = (p.z - g.origin[2]) * g.inv_cell;
+    const bool inside = fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.dims[0] && fy < (float)g.dims[1] && fz < (float)g.dims[2];
+    cell = inside ? ((uint32_t)fz * g.dims[1] + (uint32_t)fy) * g.dims[0] + (uint32_t)fx : 0u;
+    return inside;
+}
+
 template <int NP, bool COUNT>
 __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__restrict__ pa, const Float4 *__restrict__ pb, const V3 (&p)[NP],
                                           float (&acc)[NP], bool (&outside)[NP], Work (&work)[NP]) {
-    typedef uint32_t Header __attribute__((ext_vector_type(4)));
+    typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+    typedef float Float2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-        const float fx = (p[n].x - g.origin[0]) * g.inv_cell, fy = (p[n].y - g.origin[1]) * g.inv_cell, fz = (p[n].z - g.origin[2]) * g.inv_cell;
-        const bool inside = fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.dims[0] && fy < (float)g.dims[1] && fz < (float)g.dims[2];
-        outside[n] = !inside;
-        if (!inside) continue;
-        const uint32_t cell = ((uint32_t)fz * g.dims[1] + (uint32_t)fy) * g.dims[0] + (uint32_t)fx;
-        typedef uint32_t Entry __attribute__((ext_vector_type(2)));   // table row, lower bound over the cell (float bits)
-        const Header head = reinterpret_cast<const Header *>(g.cells)[cell];
-        const Entry *e = reinterpret_cast<const Entry *>(g.entries) + head[0];
-        const uint32_t n_spheres = head[1], n_boxes = head[2], n_crosses = head[3];
+        uint32_t cell;
+        outside[n] = !grid_cell_of(g, p[n], cell);
+        if (outside[n]) continue;
+        const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];   // first entry, entries
+        const Pair *e = reinterpret_cast<const Pair *>(g.entries) + head[0];
         float a = acc[n];
         const V3 q = p[n];
-        uint32_t i = 0, done_spheres = 0, done_boxes = 0, done_crosses = 0;
-        // Each class's entries come by rising lower bound: the first one whose bound is not below the running minimum ends
-        // the class (its row's distance, and every later row's, is at least that bound everywhere in the cell).  A
-        // minimum that is not a number ends nothing.  (Lists are a few rows long: unrolled loops only cost registers here.)
-        _Pragma("nounroll") for (; i < n_spheres; ++i) {
-            const Entry en = e[i];
+        uint32_t evals = 0, flops = 0;
+        // The entries come by rising lower bound: the first one whose bound is not below the running minimum ends the walk
+        // (its row's distance, and every later row's, is at least that bound everywhere in the cell).  A minimum that
+        // is not a number ends nothing.
+        _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
+            const Pair en = e[i];
             if (__uint_as_float(en[1]) >= a) break;
-            const Float4 ra = pa[en[0]];
-            const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
-            if (!sphere_cannot_change<false, false>(a, d2, ra.w)) a = __builtin_fminf(a, __builtin_sqrtf(d2) - ra.w);
-            done_spheres++;
-        }
-        _Pragma("nounroll") for (i = n_spheres; i < n_spheres + n_boxes; ++i) {
-            const Entry en = e[i];
-            if (__uint_as_float(en[1]) >= a) break;
-            a = __builtin_fminf(a, prim_distance<K_BOX>(pa[en[0]], pb[en[0]], q));
-            done_boxes++;
-        }
-        _Pragma("nounroll") for (i = n_spheres + n_boxes; i < n_spheres + n_boxes + n_crosses; ++i) {
-            const Entry en = e[i];
-            if (__uint_as_float(en[1]) >= a) break;
-            a = __builtin_fminf(a, prim_distance<K_CROSS>(pa[en[0]], pb[en[0]], q));
-            done_crosses++;
+            const uint32_t row = en[0] & 0x3fffffffu, cls = en[0] >> 30;
+            const Float4 ra = pa[row];
+            if (cls == kGridClassSphere) {
+                const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
+                if (!sphere_cannot_change<false, false>(a, d2, ra.w)) a = __builtin_fminf(a, __builtin_sqrtf(d2) - ra.w);
+                if (COUNT) flops += kFlopsSphere;
+            } else {
+                const Float2 half = *reinterpret_cast<const Float2 *>(pb + row);   // the two half sizes a box or cross keeps there
+                const Float4 rb = { half[0], half[1], 0.0f, 0.0f };
+                if (cls == kGridClassBox) {
+                    a = __builtin_fminf(a, prim_distance<K_BOX>(ra, rb, q));
+                    if (COUNT) flops += kFlopsBox;
+                } else {
+                    a = __builtin_fminf(a, prim_distance<K_CROSS>(ra, rb, q));
+                    if (COUNT) flops += kFlopsCross;
+                }
+            }
+            if (COUNT) evals++;
         }
         acc[n] = a;
         if (COUNT) {
-            work[n].evals += done_spheres + done_boxes + done_crosses;
-            work[n].flops += kFlopsSphere * done_spheres + kFlopsBox * done_boxes + kFlopsCross * done_crosses;
+            work[n].evals += evals;
+            work[n].flops += flops;
         }
+    }
+}
+
+// The same walk with the surface: which row is the smallest at p.  Of equal distances the row of the lower depth-first
+// index wins, whatever the order of the walk (fold_run's rule), so the walk ends only at a bound above the running minimum:
+// a row whose bound equals it can still tie and win by index.
+template <int NP>
+__device__ __forceinline__ void grid_surface(const GridView &g, const Float4 *__restrict__ pa, const Float4 *__restrict__ pb,
+                                             const uint32_t *__restrict__ row_prim, const V3 (&p)[NP], float (&acc)[NP], uint32_t (&accp)[NP],
+                                             bool (&outside)[NP]) {
+    typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        uint32_t cell;
+        outside[n] = !grid_cell_of(g, p[n], cell);
+        if (outside[n]) continue;
+        const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];
+        const Pair *e = reinterpret_cast<const Pair *>(g.entries) + head[0];
+        float a = acc[n];
+        uint32_t q = accp[n];
+        _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
+            const Pair en = e[i];
+            if (__uint_as_float(en[1]) > a) break;
+            const uint32_t row = en[0] & 0x3fffffffu, cls = en[0] >> 30;
+            const Float4 ra = pa[row], rb = pb[row];
+            const float v = cls == kGridClassSphere ? prim_distance<K_SPHERE>(ra, rb, p[n])
+                                                    : (cls == kGridClassBox ? prim_distance<K_BOX>(ra, rb, p[n]) : prim_distance<K_CROSS>(ra, rb, p[n]));
+            const uint32_t prim = row_prim[row];
+            const bool take = v < a || (a == v && prim < q);
+            a = take ? v : a;
+            q = take ? prim : q;
+        }
+        acc[n] = a;
+        accp[n] = q;
     }
 }
 

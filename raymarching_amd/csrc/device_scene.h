@@ -125,9 +125,11 @@ constexpr uint32_t flops_of_kind(uint32_t kind) {
 // bound (interval bounds of the distance formulas over the cell's box, body.cpp:32-57; built on the device when the
 // scene is uploaded, kernels.hip).  At a point of C the runs' fold min(acc, v_j) over all rows equals the fold over C's
 // list: a row not listed is larger than the smallest row value there, so it neither changes the minimum nor ties it.
-// A lane then evaluates about ten rows (its own cell's) where the hull walk visits hundreds for the wave.  The entries of
-// a list carry lo_j(C) and come, per class, by rising lo_j: a row whose bound is not below the running minimum cannot lower
-// it, nor can the rows after it, so the walk of a class ends there (about half the listed rows are never loaded).
+// A lane then evaluates two or three rows (its own cell's) where the hull walk visits hundreds for the wave.  The entries of
+// a list carry lo_j(C) and come by rising lo_j, the three classes mixed: a row whose bound is not below the running
+// minimum cannot lower it, nor can the rows after it, so the walk ends there -- the nearest row comes first as a rule, and
+// most of the listed rows are never loaded.  What bounds such a walk on the GPU is the address unit of the vector memory
+// path (every lane gathers from its own cell): a cell's header is 8 bytes, an entry 8, and nothing is read twice.
 // Points outside the grid's box take the hull walk.
 constexpr uint32_t kGridClassSphere = 0, kGridClassBox = 1, kGridClassCross = 2;
 constexpr uint32_t kGridMaxRuns = 8;
@@ -135,9 +137,9 @@ struct GridRun {
     uint32_t first, count, cls;   // table rows [first, first + count) (crosses: their first listing), kGridClass*
 };
 struct GridView {
-    const uint32_t *cells;     // null: no grid.  Per cell 4 words: first entry, spheres, boxes, crosses (entries in that order)
-    const uint32_t *entries;   // per entry 2 words: table row, lower bound of the row's distance over the cell (float bits);
-                               // within a class by rising bound
+    const uint32_t *cells;     // null: no grid.  Per cell 2 words: first entry, number of entries
+    const uint32_t *entries;   // per entry 2 words: table row (low 30 bits) and class (kGridClass*, high 2 bits); lower bound
+                               // of the row's distance over the cell (float bits).  By rising bound.
     float origin[3];
     float inv_cell, cell;
     uint32_t dims[3];

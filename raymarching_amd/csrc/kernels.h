@@ -28,7 +28,7 @@ hipError_t launch_eval_sdf(const SceneView &sc, const float *xyz, uint32_t n, fl
                            uint32_t *prim, float *sd_march, hipStream_t stream);
 
 // The cell grid over the root's long runs (device_scene.h: GridView), built in two passes: count_grid sizes every cell's
-// list (cells[4c + 1..3]), reserves its place (cells[4c], through the counter *total) and keeps the cell's bound H;
+// list (cells[2c + 1]), reserves its place (cells[2c], through the counter *total) and keeps the cell's bound H;
 // fill_grid writes the lists.  `total` must be zero before count_grid.
 struct GridBuild {
     GridRun runs[kGridMaxRuns];   // grouped by class: spheres, boxes, crosses
@@ -39,7 +39,7 @@ struct GridBuild {
     uint32_t *cells;
     float *bound;                 // H per cell
     unsigned long long *total;   // 64 bits: per-cell list sizes of heavily overlapping rows can sum beyond 2^32
-    uint32_t *entries;            // fill pass: 2 words per entry (table row, the row's lower bound over the cell), per class by rising bound
+    uint32_t *entries;            // fill pass: 2 words per entry (table row | class << 30, the row's lower bound over the cell), by rising bound
 };
 hipError_t launch_count_grid(const GridBuild &b, hipStream_t stream);
 hipError_t launch_fill_grid(const GridBuild &b, hipStream_t stream);

@@ -131,42 +131,36 @@ __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
             }
         b.bound[cell] = H;
     }
-    uint32_t n[3] = { 0u, 0u, 0u };
-    uint32_t at = FILL ? b.cells[4u * cell] : 0u;
-    uint32_t segment = at, segment_class = 0u;   // fill pass: where the entries of the class being listed start
+    uint32_t n = 0u;
+    const uint32_t first = FILL ? b.cells[2u * cell] : 0u;
+    uint32_t at = first;
     for (uint32_t r = 0; r < b.n_runs; ++r) {
-        if (FILL && b.runs[r].cls != segment_class) {   // the runs come grouped by class
-            segment = at;
-            segment_class = b.runs[r].cls;
-        }
         for (uint32_t i = b.runs[r].first; i < b.runs[r].first + b.runs[r].count; ++i) {
             float L, U;
             row_bounds(b.runs[r].cls, b.pa[i], b.pb[i], lo, hi, L, U);
             if (!(L > H)) {   // NaNs are listed
                 if (FILL) {
-                    // (row, lower bound of its distance anywhere in the cell), the class's entries by rising bound: the
-                    // walk stops at the first entry whose bound is not below its running minimum.  A bound that is not
-                    // a number sorts first (such a row is always evaluated).  Lists are a few entries long.
+                    // (row and class, lower bound of the row's distance anywhere in the cell), by rising bound: the walk
+                    // stops at the first entry whose bound is not below its running minimum.  A bound that is not a
+                    // number sorts first (such a row is always evaluated).  Lists are a few entries long.
                     const float key = L == L ? L : -__builtin_inff();
                     uint32_t k = at++;
-                    for (; k > segment && __uint_as_float(b.entries[2u * (k - 1u) + 1u]) > key; --k) {
+                    for (; k > first && __uint_as_float(b.entries[2u * (k - 1u) + 1u]) > key; --k) {
                         b.entries[2u * k] = b.entries[2u * (k - 1u)];
                         b.entries[2u * k + 1u] = b.entries[2u * (k - 1u) + 1u];
                     }
-                    b.entries[2u * k] = i;
+                    b.entries[2u * k] = i | b.runs[r].cls << 30;
                     b.entries[2u * k + 1u] = __float_as_uint(key);
                 } else {
-                    n[b.runs[r].cls]++;
+                    n++;
                 }
             }
         }
     }
     if (!FILL) {
         // the host uses the grid only if the 64-bit total stays below 2^28, so the 32 bits kept here are the whole offset then
-        b.cells[4u * cell] = (uint32_t)atomicAdd(b.total, (unsigned long long)(n[0] + n[1] + n[2]));
-        b.cells[4u * cell + 1u] = n[0];
-        b.cells[4u * cell + 2u] = n[1];
-        b.cells[4u * cell + 3u] = n[2];
+        b.cells[2u * cell] = (uint32_t)atomicAdd(b.total, (unsigned long long)n);
+        b.cells[2u * cell + 1u] = n;
     }
 }
 

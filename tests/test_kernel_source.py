@@ -12,8 +12,10 @@ from conftest import scene_path
 def test_generated_kernels_compile_for_gfx950(rm, name, lattice):
     src = rm.kernel_source(rm.Scene(scene_path(name)), lattice=lattice)
     assert 'extern "C" __global__' in src and "rm_trace" in src and "rm_eval_sdf" in src
-    assert "rm_trace_exact" in src and "trace_body<CompiledSceneT<false>, 1, false>" in src   # the optimistic kernel and its exact pass
+    assert "trace_body<CompiledSceneT<false>, 1, false>" in src
     assert ("lattice_level<" in src) == (lattice and name != "synthetic1024.txt")
+    assert ("rm_trace_exact" in src) == ("lattice_level<" in src)   # scenes with a lattice: the optimistic kernel's exact pass
+    assert ("grid_surface<" in src) == ("grid_fold<" in src) == (name == "synthetic1024.txt")
     assert ("fold_run_clustered<" in src) == (name == "synthetic1024.txt")
     rm.kernel_source_compiles(src)
 
