@@ -32,7 +32,7 @@ def per_launch(directory, counter):
             name = row["Kernel_Name"]
             if row.get("Grid_Size") == "64":
                 continue   # the one-pixel launch with which rm_set_scene warms a freshly loaded kernel
-            if row["Counter_Name"] == counter and (("rm_trace" in name and "counting" not in name) or "trace_kernel" in name):
+            if row["Counter_Name"] == counter and (name in ("rm_trace", "rm_trace_refill") or "trace_kernel" in name):
                 total += float(row["Counter_Value"])
                 launches.add(row["Dispatch_Id"])
     if not launches:

@@ -18,7 +18,7 @@ for part in ("a", "b"):
     sums = collections.defaultdict(float); launches = set()
     for f in glob.glob(sys.argv[1] + f"/{part}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("rm_trace"):
+            if r["Kernel_Name"] == "rm_trace" and r.get("Grid_Size", "") != "64":
                 sums[r["Counter_Name"]] += float(r["Counter_Value"]); launches.add(r["Dispatch_Id"])
     print(f"[{part}] rm_trace launches: {len(launches)}")
     for k in sorted(sums): print(f"  {k:38s} {sums[k]:.6g}")
