@@ -389,8 +389,20 @@ def main():
     # tiles the scene's exact kernel rendered again behind the optimistic one, in all frames of this process so far
     exact_tiles = sum(rr.exact_tiles() for rr in rs) if a.kernel_mode == "compiled" else 0
     overlapped_ms = sum(rr.counters()["kernel_ms"] for rr in rs) / F   # last timed frame of every context, co-scheduled
+    kernel_ms_before = kernel_ms
     if timed_kernel_ms:
         kernel_ms = overlapped_ms = sum(timed_kernel_ms) / len(timed_kernel_ms)   # one frame in flight: the timed frames themselves
+    else:
+        # The trace kernel's own duration for the roofline: frames in flight stretch each other's spans, and the frames timed
+        # during set-up ran on a GPU that idled between them (lower clocks: 0.48 against 0.45 ms for the default frame).  So:
+        # right behind the timed region, with the GPU still under load, frames one at a time, back to back, for at least
+        # 16 frames and 20 ms; the mean of the second half.
+        alone, t_alone = [], time.perf_counter()
+        while len(alone) < 16 or (time.perf_counter() - t_alone < 0.020 and len(alone) < 4096):
+            r.render_device(rows, None, shard.data_ptr())
+            alone.append(r.counters()["kernel_ms"])
+        alone = alone[len(alone) // 2:]
+        kernel_ms = sum(alone) / len(alone)
     # ---- the same frames with every sample and every ray doing the reference's full work (one GPU only; after the
     # timed region): the rate at which the frame's nominal rays are all marched
     all_marched = None
@@ -604,10 +616,11 @@ def main():
                 "in_flight_note": "executed FLOPs of a frame over the time per frame of the timed region (all GPUs; resolve and gather included): "
                                   "the sustained rate when the tails of one frame's longest tiles are filled by other frames",
                 "valu_issue": valu_issue,
-                "kernel_ms": round(kernel_ms, 4), "kernel_ms_in_timed_region": round(overlapped_ms, 4),
+                "kernel_ms": round(kernel_ms, 4), "kernel_ms_in_timed_region": round(overlapped_ms, 4), "kernel_ms_during_set_up": round(kernel_ms_before, 4),
                 "kernel_ms_note": "kernel_ms: HIP events around the trace kernel with one frame on the GPU (used for achieved): the "
-                                  "timed frames themselves with --frames-in-flight 1, frames rendered just before the timed "
-                                  "region otherwise, because frames in flight on several streams stretch each other's spans",
+                                  "timed frames themselves with --frames-in-flight 1; otherwise frames rendered one at a time, back to "
+                                  "back, right behind the timed region (frames in flight on several streams stretch each other's spans; "
+                                  "kernel_ms_during_set_up: the same measured before the region, on a GPU that idled between frames)",
                 "flops": "executed (counted primitive evaluations)",
                 "executed_flops_per_frame": int(total_exec), "sdf_calls_per_frame": int(total_sdf),
                 "prim_evals_per_sdf_call": round(cnt["prim_evals"] / max(1, cnt["sdf_calls"]), 2),

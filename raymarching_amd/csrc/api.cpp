@@ -639,6 +639,7 @@ int build_grid(rm_context *ctx) {
     for (size_t i = 0; i < runs.size(); i++) {
         b.runs[i] = runs[i];
         n_rows += runs[i].count;
+        if ((uint64_t)runs[i].first + runs[i].count > (1u << 14)) return RM_OK;   // a list entry names its table row in 14 bits: larger tables take the hull walk
     }
     b.n_runs = (uint32_t)runs.size();
     double side[3], longest = 0.0;
@@ -690,7 +691,7 @@ int build_grid(rm_context *ctx) {
     RM_HIP(hipStreamSynchronize(ctx->stream));
     // a gigabyte of lists: leave such a scene to the hull walk (the cells' 32-bit offsets are only used below this)
     if (total > grid_entry_limit()) return RM_OK;
-    RM_HIP(ctx->d_grid_entries.reserve(2u * total + 2u));   // (row and class, lower bound) per entry
+    RM_HIP(ctx->d_grid_entries.reserve(total + 2u));   // one word per entry
     b.entries = ctx->d_grid_entries.ptr;
     RM_HIP(rmdev::launch_fill_grid(b, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));

@@ -540,7 +540,7 @@ __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__res
         outside[n] = !grid_cell_of(g, p[n], cell);
         if (outside[n]) continue;
         const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];   // first entry, entries
-        const Pair *e = reinterpret_cast<const Pair *>(g.entries) + head[0];
+        const uint32_t *e = g.entries + head[0];
         float a = acc[n];
         const V3 q = p[n];
         uint32_t evals = 0, flops = 0;
@@ -548,9 +548,9 @@ __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__res
         // (its row's distance, and every later row's, is at least that bound everywhere in the cell).  A minimum that
         // is not a number ends nothing.
         _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
-            const Pair en = e[i];
-            if (__uint_as_float(en[1]) >= a) break;
-            const uint32_t row = en[0] & 0x3fffffffu, cls = en[0] >> 30;
+            const uint32_t en = e[i];
+            if (__uint_as_float(en & 0xffff0000u) >= a) break;
+            const uint32_t row = en & 0x3fffu, cls = (en >> 14) & 3u;
             const Float4 ra = pa[row];
             if (cls == kGridClassSphere) {
                 const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
@@ -591,13 +591,13 @@ __device__ __forceinline__ void grid_surface(const GridView &g, const Float4 *__
         outside[n] = !grid_cell_of(g, p[n], cell);
         if (outside[n]) continue;
         const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];
-        const Pair *e = reinterpret_cast<const Pair *>(g.entries) + head[0];
+        const uint32_t *e = g.entries + head[0];
         float a = acc[n];
         uint32_t q = accp[n];
         _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
-            const Pair en = e[i];
-            if (__uint_as_float(en[1]) > a) break;
-            const uint32_t row = en[0] & 0x3fffffffu, cls = en[0] >> 30;
+            const uint32_t en = e[i];
+            if (__uint_as_float(en & 0xffff0000u) > a) break;
+            const uint32_t row = en & 0x3fffu, cls = (en >> 14) & 3u;
             const Float4 ra = pa[row], rb = pb[row];
             const float v = cls == kGridClassSphere ? prim_distance<K_SPHERE>(ra, rb, p[n])
                                                     : (cls == kGridClassBox ? prim_distance<K_BOX>(ra, rb, p[n]) : prim_distance<K_CROSS>(ra, rb, p[n]));

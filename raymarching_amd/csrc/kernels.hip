@@ -112,6 +112,16 @@ __device__ __forceinline__ void cell_box(const GridBuild &b, uint32_t cell, floa
     }
 }
 
+// The upper 16 bits of the largest float of 8 significant bits that is not above L (a lower bound stays one when it is
+// lowered); minus infinity for a bound that is not a number (such a row is always evaluated).
+__device__ __forceinline__ uint32_t grid_bound_bits(float L) {
+    if (!(L == L)) return 0xff800000u;
+    const uint32_t bits = __float_as_uint(L);
+    uint32_t high = bits & 0xffff0000u;
+    if ((bits & 0x80000000u) && (bits & 0xffffu)) high += 0x10000u;   // negative: the next one down (larger magnitude; at worst minus infinity)
+    return high;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
     const uint32_t n_cells = b.dims[0] * b.dims[1] * b.dims[2];
@@ -140,17 +150,13 @@ __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
             row_bounds(b.runs[r].cls, b.pa[i], b.pb[i], lo, hi, L, U);
             if (!(L > H)) {   // NaNs are listed
                 if (FILL) {
-                    // (row and class, lower bound of the row's distance anywhere in the cell), by rising bound: the walk
-                    // stops at the first entry whose bound is not below its running minimum.  A bound that is not a
-                    // number sorts first (such a row is always evaluated).  Lists are a few entries long.
-                    const float key = L == L ? L : -__builtin_inff();
+                    // One word per entry -- the bound's upper 16 bits, the class, the table row (below 2^14: the host
+                    // builds no grid otherwise) -- by rising bound: the walk stops at the first entry whose bound is
+                    // not below its running minimum.  Lists are a few entries long.
+                    const uint32_t key = grid_bound_bits(L);
                     uint32_t k = at++;
-                    for (; k > first && __uint_as_float(b.entries[2u * (k - 1u) + 1u]) > key; --k) {
-                        b.entries[2u * k] = b.entries[2u * (k - 1u)];
-                        b.entries[2u * k + 1u] = b.entries[2u * (k - 1u) + 1u];
-                    }
-                    b.entries[2u * k] = i | b.runs[r].cls << 30;
-                    b.entries[2u * k + 1u] = __float_as_uint(key);
+                    for (; k > first && __uint_as_float(b.entries[k - 1u] & 0xffff0000u) > __uint_as_float(key); --k) b.entries[k] = b.entries[k - 1u];
+                    b.entries[k] = key | b.runs[r].cls << 14 | i;
                 } else {
                     n++;
                 }
