@@ -539,18 +539,18 @@ __device__ __forceinline__ void grid_fold(const GridView &g, const Float4 *__res
         uint32_t cell;
         outside[n] = !grid_cell_of(g, p[n], cell);
         if (outside[n]) continue;
-        const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];   // first entry, entries
+        const Pair head = reinterpret_cast<const Pair *>(g.cells)[cell];   // where the other entries are, the first entry
         const uint32_t *e = g.entries + head[0];
         float a = acc[n];
         const V3 q = p[n];
         uint32_t evals = 0, flops = 0;
         // The entries come by rising lower bound: the first one whose bound is not below the running minimum ends the walk
         // (its row's distance, and every later row's, is at least that bound everywhere in the cell).  A minimum that
-        // is not a number ends nothing.
-        _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
-            const uint32_t en = e[i];
-            if (__uint_as_float(en & 0xffff0000u) >= a) break;
+        // is not a number ends nothing: the end mark does.
+        uint32_t en = head[1];
+        _Pragma("nounroll") for (uint32_t i = 0; en != kGridListEnd && !(__uint_as_float(en & 0xffff0000u) >= a); ++i) {
             const uint32_t row = en & 0x3fffu, cls = (en >> 14) & 3u;
+            en = e[i];   // (there is one: the end mark at the latest)
             const Float4 ra = pa[row];
             if (cls == kGridClassSphere) {
                 const float d2 = sphere_d2(q, ra.x, ra.y, ra.z);
@@ -594,10 +594,10 @@ __device__ __forceinline__ void grid_surface(const GridView &g, const Float4 *__
         const uint32_t *e = g.entries + head[0];
         float a = acc[n];
         uint32_t q = accp[n];
-        _Pragma("nounroll") for (uint32_t i = 0; i < head[1]; ++i) {
-            const uint32_t en = e[i];
-            if (__uint_as_float(en & 0xffff0000u) > a) break;
+        uint32_t en = head[1];
+        _Pragma("nounroll") for (uint32_t i = 0; en != kGridListEnd && !(__uint_as_float(en & 0xffff0000u) > a); ++i) {
             const uint32_t row = en & 0x3fffu, cls = (en >> 14) & 3u;
+            en = e[i];
             const Float4 ra = pa[row], rb = pb[row];
             const float v = cls == kGridClassSphere ? prim_distance<K_SPHERE>(ra, rb, p[n])
                                                     : (cls == kGridClassBox ? prim_distance<K_BOX>(ra, rb, p[n]) : prim_distance<K_CROSS>(ra, rb, p[n]));

@@ -129,17 +129,21 @@ constexpr uint32_t flops_of_kind(uint32_t kind) {
 // a list carry lo_j(C) and come by rising lo_j, the three classes mixed: a row whose bound is not below the running
 // minimum cannot lower it, nor can the rows after it, so the walk ends there -- the nearest row comes first as a rule, and
 // most of the listed rows are never loaded.  What bounds such a walk on the GPU is the address unit of the vector memory
-// path (every lane gathers from its own cell): a cell's header is 8 bytes, an entry 8, and nothing is read twice.
+// path (every lane gathers from its own cell): a cell's header is 8 bytes and holds the first entry, an entry is 4 bytes, and
+// nothing is read twice.
 // Points outside the grid's box take the hull walk.
 constexpr uint32_t kGridClassSphere = 0, kGridClassBox = 1, kGridClassCross = 2;
 constexpr uint32_t kGridMaxRuns = 8;
+constexpr uint32_t kGridListEnd = 0x7f80ffffu;   // (bound +infinity: ends the walk of every running minimum that is a number)
 struct GridRun {
     uint32_t first, count, cls;   // table rows [first, first + count) (crosses: their first listing), kGridClass*
 };
 struct GridView {
-    const uint32_t *cells;     // null: no grid.  Per cell 2 words: first entry, number of entries
-    const uint32_t *entries;   // per entry 2 words: table row (low 30 bits) and class (kGridClass*, high 2 bits); lower bound
-                               // of the row's distance over the cell (float bits).  By rising bound.
+    const uint32_t *cells;     // null: no grid.  Per cell 2 words: where the list's other entries start, the list's first entry
+                               // (kGridListEnd: the cell lists nothing)
+    const uint32_t *entries;   // per entry 1 word: the upper 16 bits of a lower bound of the row's distance over the cell (a
+                               // float's sign, exponent and 7 bits: rounded down), class (kGridClass*, 2 bits), table row
+                               // (14 bits).  By rising bound; kGridListEnd ends a list.
     float origin[3];
     float inv_cell, cell;
     uint32_t dims[3];

@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void grid_kernel(const GridBuild b) {
     if (!FILL) {
         // the host uses the grid only if the 64-bit total stays below 2^28, so the 32 bits kept here are the whole offset then
         b.cells[2u * cell] = (uint32_t)atomicAdd(b.total, (unsigned long long)n);
-        b.cells[2u * cell + 1u] = n;
+        b.cells[2u * cell + 1u] = kGridListEnd;
+    } else if (at > first) {
+        // the list's first entry moves into the cell's header, the others move up, and the end mark takes the last place
+        b.cells[2u * cell + 1u] = b.entries[first];
+        for (uint32_t k = first; k + 1u < at; ++k) b.entries[k] = b.entries[k + 1u];
+        b.entries[at - 1u] = kGridListEnd;
     }
 }
 
