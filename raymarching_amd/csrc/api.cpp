@@ -624,7 +624,7 @@ unsigned long long grid_entry_limit() {
 
 // Builds the cell grid over the root's long runs (device_scene.h: GridView) on the device; leaves ctx->scene.grid empty
 // if the scene has no such runs.  The box: around the runs' primitives, a fifth of its longest side wider on every
-// side (camera and shadow rays start and end near the scene); about 4096 cells per table row, sixteen million at most.
+// side (camera and shadow rays start and end near the scene); about 8192 cells per table row, sixteen million at most.
 int build_grid(rm_context *ctx) {
     rmdev::GridView &g = ctx->scene.grid;
     g = rmdev::GridView{};
@@ -660,10 +660,11 @@ int build_grid(rm_context *ctx) {
         side[k] += 2.0 * pad;
         volume *= side[k];
     }
-    // cells per table row: finer cells list fewer rows each.  Measured on the 1024-object scene / its wide variant with
-    // the box above, ms per frame: 1024 cells per row 20.4 / 6.5, 2048 19.0 / 6.3, 4096 17.9 / 5.9, 8192 17.4 / 5.8,
-    // 16384 16.8 / 5.7 (16.8 M cells: a quarter of a gigabyte of headers); $RM_GRID_CELLS_PER_ROW overrides it for such sweeps
-    double per_row = 4096.0;
+    // cells per table row: finer cells list fewer rows each, and their headers (8 bytes a cell) miss the caches more often.
+    // Measured on the 1024-object scene / its wide variant with the box above, ms per frame: 2048 cells per row 10.27 / 2.95,
+    // 4096 10.06 / 2.84, 8192 9.80 / 2.79, 16384 9.59 / 2.78 (16.8 M cells: 134 MB of headers, four times the build);
+    // $RM_GRID_CELLS_PER_ROW overrides it for such sweeps
+    double per_row = 8192.0;
     if (const char *env = std::getenv("RM_GRID_CELLS_PER_ROW")) per_row = std::max(1.0, std::atof(env));
     const double target = std::min(double(1u << 24), std::max(4096.0, per_row * (double)n_rows));
     const double cell = std::cbrt(volume / target);
