@@ -8,6 +8,7 @@ configs[4] (1024 loose primitives, 8 lights, both scene files, 1024x768, SSAA 3)
 cell grid == hull walk (the grid switched off), cost order == natural order; oracle pixels.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -102,3 +103,42 @@ def test_grid_falls_back_when_its_lists_would_not_fit(rm, oracle):
         r.close()
     cpu, _ = oracle.Scene(text=text).render(oracle.default_params(**kw))
     assert gpu.tobytes() == cpu.tobytes()
+
+
+def test_tables_too_long_for_a_list_entry_take_the_hull_walk(rm, oracle):
+    """A list entry of the cell grid names its table row in 14 bits: a scene of 17 000 loose spheres gets no grid (every lane
+    takes the hull walk) and its frame is still the oracle's; one of 3 000 spheres gets the grid, and the same frame with it
+    switched off."""
+    rng = np.random.default_rng(17)
+    head = ["Bounds 300.0", "Camera Position 0.0 30.0 120.0", "Camera Direction 0.0 -0.25 -1.0", "Camera Up 0.0 1.0 0.0", "Camera FOV 60",
+            "Light 60.0 120.0 80.0", "Color 0.3 0.7 0.9"]
+
+    def text(n):
+        c = rng.uniform([-80, 0, -80], [80, 40, 80], (n, 3))
+        r = rng.uniform(0.2, 1.2, n)
+        return "\n".join(head + [f"Sphere {x:.3f} {y:.3f} {z:.3f} {q:.3f}" for (x, y, z), q in zip(c, r)]) + "\n"
+
+    kw = dict(width=40, height=24, kernel=1)
+
+    def frame(t):
+        r = rm.Renderer(0)
+        try:
+            r.set_params(rm.default_params(**kw))
+            r.set_scene(rm.Scene(text=t))
+            return r.render_f32()
+        finally:
+            r.close()
+
+    many = text(17000)
+    cpu, _ = oracle.Scene(text=many).render(oracle.default_params(**kw))
+    assert frame(many).tobytes() == cpu.tobytes()
+    fewer = text(3000)
+    with_grid = frame(fewer)
+    os.environ["RM_GRID_MAX_ENTRIES"] = "0"
+    try:
+        without = frame(fewer)
+    finally:
+        del os.environ["RM_GRID_MAX_ENTRIES"]
+    assert with_grid.tobytes() == without.tobytes()
+    cpu, _ = oracle.Scene(text=fewer).render(oracle.default_params(**kw))
+    assert with_grid.tobytes() == cpu.tobytes()
