@@ -480,11 +480,13 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
                   min_waves, counting ? "rm_trace_counting" : "rm_trace", counting ? "true" : "false", points_per_lane, counting ? "true" : "false");
     s += buf;
     if (!counting && s.find("exact_wanted_word") != std::string::npos) {
-        // the pass behind rm_trace over the tiles it flagged (trace_kernel.h: trace_exact_body); same workgroup shapes.
+        // the pass behind rm_trace over the tiles it flagged, which can also resolve the sample image into pixels
+        // (trace_kernel.h: trace_exact_body); same workgroup shapes.
         // Only scenes with a lattice can flag a tile: the others get no such kernel, and their renders no such launch.
         std::snprintf(buf, sizeof buf,
-                      "extern \"C\" __global__ __launch_bounds__(576, %d) void rm_trace_exact(const SceneView sc, const FrameView fr, Sample *samples) {\n"
-                      "    trace_exact_body<CompiledSceneT<true>, %d>(sc, fr, samples);\n}\n\n", min_waves, points_per_lane);
+                      "extern \"C\" __global__ __launch_bounds__(576, %d) void rm_trace_exact(const SceneView sc, const FrameView fr, Sample *samples,\n"
+                      "        float *out_f32, unsigned char *out_rgba8) {\n"
+                      "    trace_exact_body<CompiledSceneT<true>, %d>(sc, fr, samples, out_f32, out_rgba8);\n}\n\n", min_waves, points_per_lane);
         s += buf;
     }
     if (refill) {

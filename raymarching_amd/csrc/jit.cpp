@@ -368,24 +368,30 @@ hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const 
                                  lds, stream, args, nullptr);
 }
 
+bool exact_launch_can_resolve(uint32_t kernel) { return kernel * kernel <= 64u; }
+
 hipError_t launch_trace_exact_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
-                                     hipStream_t stream) {
+                                     float *out_f32, unsigned char *out_rgba8, hipStream_t stream) {
     const uint32_t sw = fr.width * fr.kernel;
     const uint32_t sh = fr.band_count * fr.band_rows * fr.kernel;
     if (sw == 0 || sh == 0 || !m.trace_exact || !fr.tile_flags) return hipSuccess;
     const uint32_t side = 8u * waves_per_side, pts = m.points_per_lane;
-    const size_t n_tiles = (size_t)((sw + side * pts - 1u) / (side * pts)) * ((sh + side - 1u) / side);
+    const uint32_t tiles_x = (sw + side * pts - 1u) / (side * pts), tiles_y = (sh + side - 1u) / side;
+    const bool resolving = out_f32 || out_rgba8;
+    if (resolving && !exact_launch_can_resolve(fr.kernel)) return hipErrorInvalidValue;   // (the caller asks first)
     SceneView sc_arg = sc;
     FrameView fr_arg = fr;
     fr_arg.tile_order = nullptr;   // whole tiles in natural order, nothing timed
     fr_arg.extra_slots = 0u;
     fr_arg.tile_cost = nullptr;
     fr_arg.slot_stats = nullptr;
-    void *args[] = { &sc_arg, &fr_arg, &samples };
+    void *args[] = { &sc_arg, &fr_arg, &samples, &out_f32, &out_rgba8 };
     const bool writes_pixels = fr.pixels_f32 || fr.pixels_rgba8;
     const uint32_t lds = (sc.lattice_words + (writes_pixels ? 3u * side * side : 0u)) * 4u;
-    return hipModuleLaunchKernel(m.trace_exact, (uint32_t)((n_tiles + 63u) / 64u), 1, 1, 64u * waves_per_side * waves_per_side, 1, 1, lds, stream,
-                                 args, nullptr);
+    // 64 tiles per workgroup; resolving: the k x k tiles behind a workgroup's (tile side)^2 pixels
+    const uint32_t gx = resolving ? (tiles_x + fr.kernel - 1u) / fr.kernel : (uint32_t)(((size_t)tiles_x * tiles_y + 63u) / 64u);
+    const uint32_t gy = resolving ? (tiles_y + fr.kernel - 1u) / fr.kernel : 1u;
+    return hipModuleLaunchKernel(m.trace_exact, gx, gy, 1, 64u * waves_per_side * waves_per_side, 1, 1, lds, stream, args, nullptr);
 }
 
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,

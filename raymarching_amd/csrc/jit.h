@@ -52,9 +52,12 @@ bool check_scene_source(const std::string &source, std::string &log);
 // LDS: the lattice tables and, when the kernel writes pixels (fr.pixels_*), the tile's sample colours.
 hipError_t launch_trace_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
                                WorkCounters *counters, hipStream_t stream);
-// The exact pass behind launch_trace_module over the same frame: one workgroup of the frame's shape per 64 tiles.
+// The exact pass behind launch_trace_module over the same frame: one workgroup of the frame's shape per 64 tiles.  With
+// out_f32 or out_rgba8 it also resolves the sample image into those pixels (one workgroup per k x k tiles then), in
+// place of launch_resolve: for SSAA kernels that exact_launch_can_resolve accepts.
+bool exact_launch_can_resolve(uint32_t kernel);
 hipError_t launch_trace_exact_module(const SceneModule &m, const SceneView &sc, const FrameView &fr, uint32_t waves_per_side, Sample *samples,
-                                     hipStream_t stream);
+                                     float *out_f32, unsigned char *out_rgba8, hipStream_t stream);
 hipError_t launch_eval_sdf_module(const SceneModule &m, const SceneView &sc, const float *xyz, uint32_t n, float *sd,
                                   uint32_t *prim, float *sd_march, hipStream_t stream);
 

@@ -502,33 +502,62 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
     }
 }
 
-// The exact kernel's pass behind an optimistic launch: workgroup b looks at tiles 64 b .. 64 b + 63 of the launch's sample
-// image and renders those whose word in FrameView::tile_flags is set, whole and in natural order, with a scene whose every
-// walk is exact; the words are cleared on the way.  Launched with the frame's workgroup shape; almost always every
-// workgroup finds nothing and ends.
+// The exact kernel's pass behind an optimistic launch: a workgroup looks at up to 64 tiles of the launch's sample image and
+// renders those whose word in FrameView::tile_flags is set, whole and in natural order, with a scene whose every walk is
+// exact; the words are cleared on the way.  Launched with the frame's workgroup shape; almost always every workgroup
+// finds nothing to render.
+// Its tiles are 64 in a row of the tile numbering (workgroup b: tiles 64 b .. 64 b + 63), or, where the launch also
+// resolves the sample image into pixels (out_f32 or out_rgba8 given; SSAA kernels that do not divide the tile's side, k x k
+// <= 64), the k x k tiles that hold the samples of its (tile side)^2 pixels -- workgroup (bx, by): tiles bx k .. bx k + k - 1
+// by by k .. by k + k - 1 -- one pixel per thread (render.cpp:103-119: the colours of the pixel's k x k samples are added up
+// over i (outer, x) then j (inner, y), divided by k x k).  One launch then takes the place of two.
 template <class Scene, int kPts>
-__device__ __forceinline__ void trace_exact_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples) {
+__device__ __forceinline__ void trace_exact_body(const SceneView &sc, const FrameView &fr, Sample *__restrict__ samples,
+                                                 float *__restrict__ out_f32, unsigned char *__restrict__ out_rgba8) {
     __shared__ unsigned long long flagged;
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t tile_side = 8u * (n_waves == 1u ? 1u : (n_waves == 4u ? 2u : 3u));
-    const uint32_t sw = fr.width * fr.kernel, sh = fr.band_count * fr.band_rows * fr.kernel;
-    const uint32_t n_tiles = ((sw + tile_side * (uint32_t)kPts - 1u) / (tile_side * (uint32_t)kPts)) * ((sh + tile_side - 1u) / tile_side);
-    const uint32_t first = blockIdx.x * 64u;
+    const uint32_t k = fr.kernel;
+    const uint32_t sw = fr.width * k, rows = fr.band_count * fr.band_rows, sh = rows * k;
+    const uint32_t tiles_x = (sw + tile_side * (uint32_t)kPts - 1u) / (tile_side * (uint32_t)kPts), tiles_y = (sh + tile_side - 1u) / tile_side;
+    const bool resolving = out_f32 != nullptr || out_rgba8 != nullptr;
+    // the i-th of this workgroup's tiles (kNoForcedTile: there is no such tile)
+    const auto tile_of = [&](uint32_t i) -> uint32_t {
+        if (!resolving) return blockIdx.x * 64u + i < tiles_x * tiles_y ? blockIdx.x * 64u + i : kNoForcedTile;
+        const uint32_t tx = blockIdx.x * k + i % k, ty = blockIdx.y * k + i / k;
+        return (i < k * k && tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : kNoForcedTile;
+    };
     if (threadIdx.x < 64u) {
-        const uint32_t t = first + threadIdx.x;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(t < n_tiles && fr.tile_flags[t] != 0u);
+        const uint32_t t = tile_of(threadIdx.x);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(t != kNoForcedTile && fr.tile_flags[t] != 0u);
         if (threadIdx.x == 0u) flagged = mask;
     }
     __syncthreads();
     unsigned long long todo = flagged;   // the same for every wave
     for (; todo != 0ull; todo &= todo - 1ull) {
-        const uint32_t tile = first + (uint32_t)__builtin_ctzll(todo);
+        const uint32_t tile = tile_of((uint32_t)__builtin_ctzll(todo));
         if (threadIdx.x == 0u) {
             fr.tile_flags[tile] = 0u;
             if (fr.exact_count) atomicAdd(fr.exact_count, 1u);
         }
         trace_body<Scene, kPts, false>(sc, fr, samples, nullptr, tile);
-        __syncthreads();   // the tile's LDS (tables, sample colours, counters) is free for the next one
+        __syncthreads();   // the tile's LDS (tables, sample colours, counters) is free for the next one; its samples are written
+    }
+    if (!resolving) return;
+    const size_t row_samples = sw;
+    for (uint32_t q = 0; q < (uint32_t)kPts; ++q) {
+        const uint32_t x = (blockIdx.x * (uint32_t)kPts + q) * tile_side + threadIdx.x % tile_side, y = blockIdx.y * tile_side + threadIdx.x / tile_side;
+        if (x >= fr.width || y >= rows) continue;
+        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+        for (uint32_t i = 0; i < k; ++i) {
+            for (uint32_t j = 0; j < k; ++j) {
+                const V3 c = sample_colour(sc.colors, samples[((size_t)y * k + j) * row_samples + (size_t)x * k + i]);
+                tx += c.x;
+                ty += c.y;
+                tz += c.z;
+            }
+        }
+        store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
     }
 }
 

@@ -29,12 +29,14 @@ def _render(rm, scene, compiled, renders=1, **kw):
 
 
 @pytest.mark.parametrize("kw", [dict(width=203, height=117, kernel=3), dict(width=160, height=96, kernel=2),
-                                dict(width=96, height=64, kernel=5), dict(width=64, height=40, kernel=1)],
-                         ids=["k3", "k2", "k5", "k1"])
+                                dict(width=96, height=64, kernel=5), dict(width=64, height=40, kernel=1),
+                                dict(width=37, height=22, kernel=9)],
+                         ids=["k3", "k2", "k5", "k1", "k9"])
 def test_every_tile_marked_gives_the_same_frame(rm, monkeypatch, kw):
     """A build of the scene's kernels in which the frame's kernel marks every tile: the exact kernel renders the whole
     frame over it -- with and without a sample image between the kernels, in natural and in cost order -- and the frame is
-    the record walker's."""
+    the record walker's.  k = 3, 5: the exact kernel's launch also resolves the sample image (one workgroup per k x k tiles);
+    k = 9: too many tiles per workgroup for that, the resolve kernel follows it; k = 1, 2: no sample image."""
     scene = rm.Scene(scene_path("default.txt"))
     (walked,), none = _render(rm, scene, False, **kw)
     assert none == 0
