@@ -72,7 +72,7 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus
 
 # Frames in flight run on one HIP stream each; HIP maps streams onto this many hardware queues per process
 # (its default, 4, would let only four frames overlap).  Read when the runtime starts, hence set before torch.
-# A sharded run keeps up to 8 frames in flight (16 tried), and the collective's own stream must not share a queue
+# A sharded run keeps 4 frames in flight (up to 16 in sweeps), and the collective's own stream must not share a queue
 # with a frame's: a gather waiting for its frame would hold up the frames queued behind it.
 _QUEUES = 24 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--emulate-share" in sys.argv or "--force-collective" in sys.argv) else 8
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < _QUEUES:
@@ -98,8 +98,7 @@ def parse():
     ap.add_argument("--evaluator", default="lattice", choices=["lattice", "exhaustive"])
     ap.add_argument("--kernel-mode", default="compiled", choices=["compiled", "interpreted"])
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="contexts/streams per GPU that alternate frames (default: 4, and 8 from eight GPUs on, "
-                         "where one rank's share of a frame is short against its longest-running tiles)")
+                    help="contexts/streams per GPU that alternate frames (default: 4 at every rank count)")
     ap.add_argument("--frames-per-gather", type=int, default=0,
                     help="frames whose shards go to rank 0 in one collective (default 1)")
     ap.add_argument("--emulate-share", type=int, default=0,
