@@ -1037,12 +1037,27 @@ int render_host(rm_context *ctx, float *host_f32, uint8_t *host_rgba8) {
     const rm_rows whole = { ctx->params.height, 0, 1, 1 };
     const size_t pixels = (size_t)ctx->params.width * ctx->params.height;
     RM_HIP(hipSetDevice(ctx->device));
+    // An 8-bit image in page-locked memory is written by the resolve pass itself where there is one (rows of 64 pixels, 256
+    // bytes a wave: the copy's 3 MB cross the bus while the pass runs instead of behind it).  Not where the trace
+    // kernel writes the pixels (2 x 2-pixel tiles: 8-byte pieces), and not for frames in flight (rm_enqueue_host copies:
+    // kernels that wait for the bus hold the compute units other frames could use).  $RM_DIRECT_HOST=0: always copy.
+    unsigned char *direct = nullptr;
+    static const bool direct_allowed = [] { const char *e = std::getenv("RM_DIRECT_HOST"); return !(e && e[0] == '0'); }();
+    const bool resolve_pass = !(ctx->kernel_mode == RM_KERNEL_COMPILED && ctx->module.loaded() &&
+                                (8u * (ctx->program.lattice.size() > 1024 ? 2u : 1u)) % ctx->params.kernel == 0u);
+    if (host_rgba8 && !host_f32 && direct_allowed && resolve_pass) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, host_rgba8) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+            direct = static_cast<unsigned char *>(at.devicePointer);
+        else
+            (void)hipGetLastError();   // pageable memory: not an error here
+    }
     if (host_f32) RM_HIP(ctx->d_frame_f32.reserve(pixels * 4));
-    if (host_rgba8) RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
-    if (int rc = enqueue_bands(ctx, whole, host_f32 ? ctx->d_frame_f32.ptr : nullptr, host_rgba8 ? ctx->d_frame_rgba8.ptr : nullptr, true))
+    if (host_rgba8 && !direct) RM_HIP(ctx->d_frame_rgba8.reserve(pixels * 4));
+    if (int rc = enqueue_bands(ctx, whole, host_f32 ? ctx->d_frame_f32.ptr : nullptr, host_rgba8 ? (direct ? direct : ctx->d_frame_rgba8.ptr) : nullptr, true))
         return rc;
     if (host_f32) RM_HIP(hipMemcpyAsync(host_f32, ctx->d_frame_f32.ptr, pixels * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (host_rgba8) RM_HIP(hipMemcpyAsync(host_rgba8, ctx->d_frame_rgba8.ptr, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_rgba8 && !direct) RM_HIP(hipMemcpyAsync(host_rgba8, ctx->d_frame_rgba8.ptr, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
     return finish_bands(ctx);
 }
 
