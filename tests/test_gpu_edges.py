@@ -197,3 +197,44 @@ def test_slot_statistics_cover_every_workgroup(rm, renderer):
     assert len(st) == n_tiles + renderer.counters()["tile_parts"]
     renderer.render_f32()
     assert len(renderer.slot_stats()) == 0          # off again: nothing recorded
+
+
+def test_host_image_written_by_the_resolve_pass(rm):
+    """rm_render_rgba8 into page-locked memory: where a resolve pass follows the trace kernel (SSAA 3) that pass writes the
+    host image itself, elsewhere (SSAA 2: the trace kernel writes the pixels) and for pageable memory a copy follows the
+    kernels.  Memory from rm_host_alloc, pages of the caller's own (registered where the machine allows it), an address
+    inside them, a pageable array: the same bytes every time."""
+    import ctypes as C
+    r = rm.Renderer(0)
+    try:
+        r.set_scene(rm.Scene(scene_path("default.txt")))
+        for kw in (dict(width=203, height=117, kernel=3), dict(width=160, height=96, kernel=2)):
+            p = rm.default_params(**kw)
+            r.set_params(p)
+            want = r.render_rgba8()                                   # pageable
+            n = p.width * p.height * 4
+            locked = rm.HostBuffer((p.height, p.width, 4), np.uint8)
+            try:
+                for _ in range(2):                                    # first render times the tiles, second runs in cost order
+                    locked.array[...] = 7
+                    assert rm.lib().rm_render_rgba8(r._h, locked.ptr) == 0
+                    assert locked.array.tobytes() == want.tobytes(), kw
+            finally:
+                locked.free()
+            import mmap
+            pages = mmap.mmap(-1, (n + 4096 + 4095) // 4096 * 4096)   # whole pages of the caller's own (a small heap block does not register)
+            own = np.frombuffer(pages, np.uint8)
+            registered = rm.lib().rm_host_register(own.ctypes.data, own.nbytes) == 0   # (some machines refuse to lock a process's own pages)
+            try:
+                for offset in (0, 1024):                              # (1024: not the start of the registered range)
+                    own[...] = 9
+                    assert rm.lib().rm_render_rgba8(r._h, own.ctypes.data + offset) == 0
+                    assert own[offset:offset + n].tobytes() == want.tobytes(), (kw, offset, registered)
+                    assert (own[:offset] == 9).all() and (own[offset + n:] == 9).all()
+            finally:
+                if registered:
+                    assert rm.lib().rm_host_unregister(own.ctypes.data) == 0
+                del own
+                pages.close()
+    finally:
+        r.close()
