@@ -964,7 +964,15 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     const int ix = nearest_index(p.x, x0, inv, N - 1), iy = nearest_index(p.y, y0, inv, N - 1), iz = nearest_index(p.z, z0, inv, N - 1);
     const float dx = __builtin_fabsf(p.x - X[ix]) - h, dy = __builtin_fabsf(p.y - Y[iy]) - h, dz = __builtin_fabsf(p.z - Z[iz]) - h;
     const uint32_t ox = ONES[ix], oy = ONES[iy], oz = ONES[iz];
-    if (!((h + tau) * inv <= 0.45f)) {
+    // Long rows (27 cells and more): where two or three of them are wanted, the same single crosses are folded first --
+    // the row through the two smallest axis terms then sets a bar that the other rows, as a rule, do not pass, and they
+    // are never walked.
+    bool several_rows = false;
+    if (N >= 27) {
+        const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
+        several_rows = (bx && by && bz) && ((!(ox & oy) ? 1 : 0) + (!(ox & oz) ? 1 : 0) + (!(oy & oz) ? 1 : 0)) >= 2;
+    }
+    if (several_rows || !((h + tau) * inv <= 0.45f)) {
         // More than one centre per axis could be in range: the running value is far below what this level is worth at p
         // (in a fine tunnel, away from the coarse ones, it is still minus the depth inside the sponge's box).  One cross
         // of each row through the nearest centres is folded first -- see lattice_nearest_rows: values of real crosses, so
@@ -990,9 +998,22 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
         if (!((h + tau) * inv <= 0.45f)) return kLatticeGeneral;
     }
     const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
-    const bool rz = bx && by && !(ox & oy), ry = bx && bz && !(ox & oz), rx = by && bz && !(oy & oz);
+    const bool rz = bx && by && !(ox & oy);
+    bool ry = bx && bz && !(ox & oz), rx = by && bz && !(oy & oz);
     run = lattice_rows<2, COUNT>(rz, Z, ONES, N, p.z, h, dx, dy, ox | oy, run);
+    // a row that has been walked raises the running value, and with it the bar for the rows still to come: they are
+    // tested again (the same test, against the value as it is now) -- where a row is long enough for that to pay (Menger-6
+    // close-up 9.69 -> 8.40 ms per frame; with the rows of 3 and 9 cells tested again too the default frame lost 2 %)
+    if (N >= 27 && rz && (ry || rx)) {
+        tau = eps - run;
+        ry = ry && dx < tau && dz < tau;
+        rx = rx && dy < tau && dz < tau;
+    }
     run = lattice_rows<1, COUNT>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
+    if (N >= 27 && ry && rx) {
+        tau = eps - run;
+        rx = dy < tau && dz < tau;
+    }
     run = lattice_rows<0, COUNT>(rx, X, ONES, N, p.x, h, dy, dz, oy | oz, run);
     if (COUNT) n_evals += (uint32_t)N * ((rz ? 1u : 0u) + (ry ? 1u : 0u) + (rx ? 1u : 0u));
     return kLatticeNext;
