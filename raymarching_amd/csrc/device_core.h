@@ -942,6 +942,11 @@ __device__ __forceinline__ uint32_t *exact_wanted_word() {
 // pass its early-out because coarser levels have larger half-widths).
 constexpr int kLatticeDone = 0, kLatticeNext = 1, kLatticeGeneral = 2;
 
+// rows of at least this many cells count as long (below: the tests that spare a long row its walk)
+#ifndef RM_LONG_ROW
+#define RM_LONG_ROW 27
+#endif
+
 template <int N, bool COUNT>
 __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float inv, float x0, float y0, float z0, V3 p, float eps,
                                              float &run, uint32_t &n_evals) {
@@ -968,7 +973,7 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     // the row through the two smallest axis terms then sets a bar that the other rows, as a rule, do not pass, and they
     // are never walked.
     bool several_rows = false;
-    if (N >= 27) {
+    if (N >= RM_LONG_ROW) {
         const bool bx = dx < tau, by = dy < tau, bz = dz < tau;
         several_rows = (bx && by && bz) && ((!(ox & oy) ? 1 : 0) + (!(ox & oz) ? 1 : 0) + (!(oy & oz) ? 1 : 0)) >= 2;
     }
@@ -1004,13 +1009,13 @@ __device__ __forceinline__ int lattice_level(const uint32_t *tab, float h, float
     // a row that has been walked raises the running value, and with it the bar for the rows still to come: they are
     // tested again (the same test, against the value as it is now) -- where a row is long enough for that to pay (Menger-6
     // close-up 9.69 -> 8.40 ms per frame; with the rows of 3 and 9 cells tested again too the default frame lost 2 %)
-    if (N >= 27 && rz && (ry || rx)) {
+    if (N >= RM_LONG_ROW && rz && (ry || rx)) {
         tau = eps - run;
         ry = ry && dx < tau && dz < tau;
         rx = rx && dy < tau && dz < tau;
     }
     run = lattice_rows<1, COUNT>(ry, Y, ONES, N, p.y, h, dx, dz, ox | oz, run);
-    if (N >= 27 && ry && rx) {
+    if (N >= RM_LONG_ROW && ry && rx) {
         tau = eps - run;
         rx = dy < tau && dz < tau;
     }
