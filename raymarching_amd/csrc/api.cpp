@@ -221,8 +221,11 @@ namespace {
 // order still holds: shipped scene 0.476 / 0.460 / 0.447 at 6 / 7 / 8 waves.)
 constexpr int kCompiledPts = 1, kCompiledWaves = 8;
 // how many of the longest tiles are launched in 16 and in 4 parts; $RM_SPLIT_TILES=S,Q overrides the counts for sweeps
-// (orders in the cache directory are not keyed by them: sweep with the cache off)
-struct SplitCounts { size_t sixteenths = 16, quarters = 32; };
+// (orders in the cache directory are not keyed by them: sweep with the cache off).  Parts cost waves; what they buy is a
+// shorter wait for the frame's longest workgroup, which matters the less the shorter that workgroup runs.  Default
+// frame, same GPU, ms per frame in flight / rank 0's eighth share alone: no parts 0.439 / 0.252, (2, 4) 0.440 / 0.207,
+// (4, 16) 0.441 / 0.184, (8, 16) 0.442 / 0.184, (16, 32) 0.448 / 0.180, (32, 64) 0.454 / 0.181.
+struct SplitCounts { size_t sixteenths = 4, quarters = 16; };
 const SplitCounts &split_counts() {
     static const SplitCounts counts = [] {
         SplitCounts c;
