@@ -144,7 +144,9 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes,
 
 /* Replaces render::GPU (render.cpp:468-475): renders the whole frame and
  * copies it into the caller's host buffer, width*height*4 bytes, row 0 = top,
- * RGBA8 = round(clamp(c,0,1)*255), alpha 255. */
+ * RGBA8 = round(clamp(c,0,1)*255), alpha 255.  An image in page-locked memory
+ * (rm_host_alloc, rm_host_register) arrives faster; where a resolve pass follows
+ * the trace kernel it is written by that pass itself instead of copied. */
 int rm_render_rgba8(rm_context *ctx, uint8_t *host_image);
 
 /* Same frame as float RGBA (the CPU operators' Image2D<float4>, render.cpp:119),
