@@ -99,3 +99,23 @@ def test_camera_inside_the_material(rm, oracle):
     assert walked.tobytes() == cpu.tobytes()
     assert gpu.tobytes() == cpu.tobytes()
     print("tiles rendered again:", tiles)
+
+
+@pytest.mark.parametrize("iterations,camera,whole", [
+    (5, ("-1.1134 5.3313 -44.9354", "0.4565 0.6824 0.5709"), True),
+    (6, ("8.7631 10.1043 -51.0847", "-0.1227 0.3563 0.9263"), False)], ids=["inside-5", "grazing-6"])
+def test_cameras_that_need_the_exact_kernel(rm, iterations, camera, whole):
+    """Two cameras a random search found (tools/soak_lattice.py): one inside the material of a Menger-5 sponge, where the frame's
+    kernel marks every tile, one at a Menger-6 sponge where two tiles are marked.  The frames are the record walker's (its own
+    lattice walk), in natural and in cost order."""
+    kw = dict(width=96, height=64, kernel=2)
+    text = "\n".join(["Bounds 200.0", "Camera Position " + camera[0], "Camera Direction " + camera[1], "Camera Up 0.0 1.0 0.0", "Camera FOV 70",
+                      "Light -15.0 40.0 -20.0", "Light 45.0 50.0 -35.0", "Box 0.0 -1.0 -50.0 75.0 2.0 75.0", "Color 1.0 1.0 1.0",
+                      f"MengerSponge 0.0 10.0 -50.0 20.0 {iterations}"]) + "\n"
+    scene = rm.Scene(text=text)
+    (first, second), tiles = _render(rm, scene, True, renders=2, **kw)
+    (walked,), _ = _render(rm, scene, False, **kw)
+    assert first.tobytes() == walked.tobytes() and second.tobytes() == walked.tobytes()
+    assert tiles > 0 and tiles % 2 == 0
+    if whole:
+        assert tiles == 2 * (96 * 2 // 8) * (64 * 2 // 8)
