@@ -549,8 +549,32 @@ def main():
             for _ in range(n_m):
                 m.render_device(out_m.data_ptr())
             multi_ms = (time.perf_counter() - t1) / n_m * 1e3
+            # the same with three frames in flight: three such objects take turns (rm_multi_enqueue_device / rm_multi_wait)
+            others, outs = [], [out_m]
+            for _ in range(2):
+                mm = rm.MultiRenderer([local] * 4)
+                mm.set_params(params)
+                mm.set_scene(scene)
+                outs.append(torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"))
+                for _ in range(3):
+                    mm.render_device(outs[-1].data_ptr())
+                others.append(mm)
+            ring = [m] + others
+            n_p = 3 * max(4, min(a.steps, 60) // 3)
+            t1 = time.perf_counter()
+            for i in range(n_p):
+                q = ring[i % 3]
+                q.wait()
+                q.enqueue_device(outs[i % 3].data_ptr())
+            for q in ring:
+                q.wait()
+            piped_ms = (time.perf_counter() - t1) / n_p * 1e3
+            piped_equal = all(bool(torch.equal(o, single)) for o in outs)
+            for mm in others:
+                mm.close()
             native_multi = {"ranks": 4, "devices": [local] * 4, "transport": "copies" if m.transport == rm.MULTI_COPY else "rccl",
                             "frame_ms": round(multi_ms, 4), "frame_equals_single_launch": bool(torch.equal(out_m, single)),
+                            "frame_ms_three_in_flight": round(piped_ms, 4), "frames_in_flight_equal_single_launch": piped_equal,
                             "note": "rm_multi_render_device: the frame's 4-row bands dealt to four contexts of this one GPU, shares gathered and "
                                     "de-interleaved on rank 0, one frame at a time (a functional rehearsal of the one-process multi-GPU path, "
                                     "not a scaling figure)"}

@@ -420,6 +420,14 @@ int rm_multi_set_scene_from(rm_multi *m, const rm_scene *scene);
  * (width * height * 4 bytes, row 0 = top), or into device memory on rank 0's device. */
 int rm_multi_render_rgba8(rm_multi *m, uint8_t *host_image);
 int rm_multi_render_device(rm_multi *m, uint8_t *device_rgba8);
+/* The same without waiting (no counterpart in the reference, whose render::GPU blocks): the frame's kernels, exchange and
+ * final copy are queued on the ranks' streams and the call returns; rm_multi_wait waits for them.  One frame at a time per
+ * rm_multi: several rm_multi objects over the same devices keep several frames in flight (a rank's longest tiles then
+ * overlap the next frame's start).  Each object's first frame of a configuration still renders synchronously, rank after
+ * rank (it times the tiles).  host_image should be page-locked (rm_host_alloc) for the copy to overlap anything. */
+int rm_multi_enqueue_rgba8(rm_multi *m, uint8_t *host_image);
+int rm_multi_enqueue_device(rm_multi *m, uint8_t *device_rgba8);
+int rm_multi_wait(rm_multi *m);
 /* Rank r's context (settings such as rm_set_kernel_mode or rm_set_shading before the scene is set, counters after a
  * frame), the number of ranks, and the transport in use (RM_MULTI_RCCL or RM_MULTI_COPY). */
 rm_context *rm_multi_context(rm_multi *m, uint32_t rank);

@@ -14,7 +14,7 @@ EXPORTS = (
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
     "rm_multi_create", "rm_multi_destroy", "rm_multi_set_params", "rm_multi_set_scene", "rm_multi_set_scene_from",
-    "rm_multi_render_rgba8", "rm_multi_render_device", "rm_multi_context", "rm_multi_ranks", "rm_multi_transport_in_use",
+    "rm_multi_render_rgba8", "rm_multi_render_device", "rm_multi_enqueue_rgba8", "rm_multi_enqueue_device", "rm_multi_wait", "rm_multi_context", "rm_multi_ranks", "rm_multi_transport_in_use",
 )
 
 
@@ -131,6 +131,9 @@ def lib():
     L.rm_multi_set_scene_from.argtypes = [vp, vp]
     L.rm_multi_render_rgba8.argtypes = [vp, vp]
     L.rm_multi_render_device.argtypes = [vp, vp]
+    L.rm_multi_enqueue_rgba8.argtypes = [vp, vp]
+    L.rm_multi_enqueue_device.argtypes = [vp, vp]
+    L.rm_multi_wait.argtypes = [vp]
     L.rm_multi_context.argtypes = [vp, C.c_uint32]
     L.rm_multi_context.restype = vp
     L.rm_multi_ranks.argtypes = [vp]
@@ -436,6 +439,17 @@ class MultiRenderer:
 
     def render_device(self, rgba8_ptr):
         _check(lib().rm_multi_render_device(self._h, rgba8_ptr), "rm_multi_render_device")
+
+    def enqueue_device(self, rgba8_ptr):
+        """render_device without waiting; pair with wait()."""
+        _check(lib().rm_multi_enqueue_device(self._h, rgba8_ptr), "rm_multi_enqueue_device")
+
+    def enqueue_rgba8(self, host_ptr):
+        """The frame into (page-locked) host memory at address host_ptr without waiting; pair with wait()."""
+        _check(lib().rm_multi_enqueue_rgba8(self._h, host_ptr), "rm_multi_enqueue_rgba8")
+
+    def wait(self):
+        _check(lib().rm_multi_wait(self._h), "rm_multi_wait")
 
 
 class HostBuffer:

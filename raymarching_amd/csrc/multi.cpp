@@ -107,6 +107,7 @@ struct rm_multi {
     size_t stack_bytes = 0, frame_bytes = 0;
     size_t shard_capacity = 0;
     hipEvent_t gathered = nullptr;
+    bool in_flight = false;           // rm_multi_enqueue_* has queued a frame that rm_multi_wait has not waited for
 };
 
 namespace {
@@ -316,6 +317,7 @@ int rm_multi_create(const int *devices, uint32_t n_devices, int transport, rm_mu
 
 int rm_multi_destroy(rm_multi *m) {
     if (!m) return RM_OK;
+    if (m->in_flight) (void)rm_multi_wait(m);
     for (Rank &k : m->ranks)
         if (k.ctx) (void)rm_wait(k.ctx);
     for (Rank &k : m->ranks)
@@ -337,6 +339,7 @@ int rm_multi_destroy(rm_multi *m) {
 
 int rm_multi_set_params(rm_multi *m, const rm_params *params) {
     if (!m || !params) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_set_params: null argument");
+    if (int rc = rm_multi_wait(m)) return rc;
     for (Rank &k : m->ranks) {
         if (int rc = rm_set_params(k.ctx, params)) return rc;
         k.ordered = false;
@@ -349,6 +352,7 @@ int rm_multi_set_params(rm_multi *m, const rm_params *params) {
 int rm_multi_set_scene(rm_multi *m, const rm_node *nodes, uint32_t n_nodes, const float *lights_xyz, uint32_t n_lights,
                        const float transform[16], float focal) {
     if (!m) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_set_scene: null argument");
+    if (int rc = rm_multi_wait(m)) return rc;
     m->have_scene = false;
     for (Rank &k : m->ranks) {
         // the first rank compiles the scene's kernels; the others find the code object in the process's cache
@@ -371,22 +375,43 @@ int rm_multi_set_scene_from(rm_multi *m, const rm_scene *scene) {
     return rm_multi_set_scene(m, nodes.data(), n_nodes, lights.data(), n_lights, transform, focal);
 }
 
-int rm_multi_render_device(rm_multi *m, uint8_t *device_rgba8) {
-    if (!m || !device_rgba8) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_render_device: null argument");
+int rm_multi_enqueue_device(rm_multi *m, uint8_t *device_rgba8) {
+    if (!m || !device_rgba8) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_enqueue_device: null argument");
+    if (m->in_flight) return rm_internal_fail(RM_ERR_STATE, "rm_multi_enqueue_device: a frame is in flight (rm_multi_wait first)");
     if (int rc = render_frame(m)) return rc;
     hipStream_t stream0 = static_cast<hipStream_t>(rm_stream(m->ranks[0].ctx));
     RM_MHIP(hipMemcpyAsync(device_rgba8, m->frame, (size_t)m->params.width * m->params.height * 4u, hipMemcpyDeviceToDevice, stream0));
     RM_MHIP(hipEventRecord(m->gathered, stream0));
-    return finish_frame(m);
+    m->in_flight = true;
+    return RM_OK;
 }
 
-int rm_multi_render_rgba8(rm_multi *m, uint8_t *host_image) {
-    if (!m || !host_image) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_render_rgba8: null argument");
+int rm_multi_enqueue_rgba8(rm_multi *m, uint8_t *host_image) {
+    if (!m || !host_image) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_enqueue_rgba8: null argument");
+    if (m->in_flight) return rm_internal_fail(RM_ERR_STATE, "rm_multi_enqueue_rgba8: a frame is in flight (rm_multi_wait first)");
     if (int rc = render_frame(m)) return rc;
     hipStream_t stream0 = static_cast<hipStream_t>(rm_stream(m->ranks[0].ctx));
     RM_MHIP(hipMemcpyAsync(host_image, m->frame, (size_t)m->params.width * m->params.height * 4u, hipMemcpyDeviceToHost, stream0));
     RM_MHIP(hipEventRecord(m->gathered, stream0));
+    m->in_flight = true;
+    return RM_OK;
+}
+
+int rm_multi_wait(rm_multi *m) {
+    if (!m) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_wait: null argument");
+    if (!m->in_flight) return RM_OK;
+    m->in_flight = false;
     return finish_frame(m);
+}
+
+int rm_multi_render_device(rm_multi *m, uint8_t *device_rgba8) {
+    if (int rc = rm_multi_enqueue_device(m, device_rgba8)) return rc;
+    return rm_multi_wait(m);
+}
+
+int rm_multi_render_rgba8(rm_multi *m, uint8_t *host_image) {
+    if (int rc = rm_multi_enqueue_rgba8(m, host_image)) return rc;
+    return rm_multi_wait(m);
 }
 
 rm_context *rm_multi_context(rm_multi *m, uint32_t rank) { return (m && rank < m->ranks.size()) ? m->ranks[rank].ctx : nullptr; }

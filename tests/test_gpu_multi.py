@@ -80,3 +80,53 @@ def test_multi_argument_errors(rm):
             m.render_rgba8(out=np.zeros(4, np.uint8).ctypes.data)
     finally:
         m.close()
+
+
+def test_multi_frames_in_flight(rm):
+    """rm_multi_enqueue_* / rm_multi_wait: two multi-rank objects over the same GPU take turns, frames into device memory and
+    into page-locked host memory; every frame equals the single launch's; a second enqueue without a wait is refused, and
+    the setters wait for the frame in flight."""
+    import torch
+    p = rm.default_params(width=203, height=117, kernel=3)
+    scene = rm.Scene(scene_path("default.txt"))
+    r = rm.Renderer(0)
+    r.set_params(p)
+    r.set_scene(scene)
+    want = r.render_rgba8()
+    r.close()
+    ms = [rm.MultiRenderer([0, 0, 0]) for _ in range(2)]
+    host = [rm.HostBuffer((p.height, p.width, 4), np.uint8) for _ in range(2)]
+    try:
+        for m in ms:
+            m.set_params(p)
+            m.set_scene(scene)
+        dev = [torch.zeros((p.height, p.width, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for i in range(8):                        # the first frame of each object is its synchronous, tile-timing one
+            m = ms[i % 2]
+            m.wait()
+            if i >= 2:
+                assert dev[i % 2].cpu().numpy().tobytes() == want.tobytes(), i
+                dev[i % 2].zero_()
+            m.enqueue_device(dev[i % 2].data_ptr())
+        with pytest.raises(rm.RaymarchError):
+            ms[0].enqueue_device(dev[0].data_ptr())          # one frame at a time per object
+        for m in ms:
+            m.wait()
+        for i in range(4):
+            m = ms[i % 2]
+            m.wait()
+            if i >= 2:
+                assert host[i % 2].array.tobytes() == want.tobytes(), i
+            host[i % 2].array[...] = 0
+            m.enqueue_rgba8(host[i % 2].ptr)
+        ms[0].set_params(p)                                   # waits for the frame in flight
+        assert host[0].array.tobytes() == want.tobytes()
+        ms[1].wait()
+        assert host[1].array.tobytes() == want.tobytes()
+        ms[0].set_scene(scene)
+        assert ms[0].render_rgba8().tobytes() == want.tobytes()
+    finally:
+        for m in ms:
+            m.close()
+        for h in host:
+            h.free()
