@@ -530,56 +530,61 @@ def main():
                         "per synchronous call (rm_render_device / rm_render_rgba8 into page-locked / pageable memory)"}
         for hb in bufs:
             hb.free()
-    # ---- the one-process sharded path (rm_multi_*): four ranks, all on this GPU (shares gathered by copies; with distinct
-    # devices the same calls gather with RCCL send/recv), one frame at a time into device memory; after the timed region
+    # ---- the one-process sharded path (rm_multi_*): four ranks, all on this GPU -- the ranks' kernels store their rows
+    # straight into the caller's frame (what the library chooses where every device can write the first one's memory), and
+    # for comparison shares gathered by copies (with distinct devices without peer access the same calls gather with RCCL
+    # send/recv) -- one frame at a time and three in flight, into device memory; after the timed region
     native_multi = None
     if world == 1 and not group and a.emulate_share <= 1 and not a.no_host_leg:
-        m = rm.MultiRenderer([local] * 4)
-        try:
-            m.set_params(params)
-            m.set_scene(scene)
-            whole_rows = rm.Rows(H, 0, 1, 1)
-            single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-            r.render_device(whole_rows, None, single.data_ptr())
-            out_m = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
-            for _ in range(4):
-                m.render_device(out_m.data_ptr())
-            n_m = max(8, min(a.steps, 50))
-            t1 = time.perf_counter()
-            for _ in range(n_m):
-                m.render_device(out_m.data_ptr())
-            multi_ms = (time.perf_counter() - t1) / n_m * 1e3
-            # the same with three frames in flight: three such objects take turns (rm_multi_enqueue_device / rm_multi_wait)
-            others, outs = [], [out_m]
-            for _ in range(2):
-                mm = rm.MultiRenderer([local] * 4)
-                mm.set_params(params)
-                mm.set_scene(scene)
-                outs.append(torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"))
+        whole_rows = rm.Rows(H, 0, 1, 1)
+        single = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        r.render_device(whole_rows, None, single.data_ptr())
+        names = {rm.MULTI_COPY: "copies", rm.MULTI_RCCL: "rccl", rm.MULTI_DIRECT: "direct stores"}
+
+        def multi_leg(transport):
+            ring, outs = [], []
+            try:
                 for _ in range(3):
-                    mm.render_device(outs[-1].data_ptr())
-                others.append(mm)
-            ring = [m] + others
-            n_p = 3 * max(4, min(a.steps, 60) // 3)
-            t1 = time.perf_counter()
-            for i in range(n_p):
-                q = ring[i % 3]
-                q.wait()
-                q.enqueue_device(outs[i % 3].data_ptr())
-            for q in ring:
-                q.wait()
-            piped_ms = (time.perf_counter() - t1) / n_p * 1e3
-            piped_equal = all(bool(torch.equal(o, single)) for o in outs)
-            for mm in others:
-                mm.close()
-            native_multi = {"ranks": 4, "devices": [local] * 4, "transport": "copies" if m.transport == rm.MULTI_COPY else "rccl",
-                            "frame_ms": round(multi_ms, 4), "frame_equals_single_launch": bool(torch.equal(out_m, single)),
-                            "frame_ms_three_in_flight": round(piped_ms, 4), "frames_in_flight_equal_single_launch": piped_equal,
-                            "note": "rm_multi_render_device: the frame's 4-row bands dealt to four contexts of this one GPU, shares gathered and "
-                                    "de-interleaved on rank 0, one frame at a time (a functional rehearsal of the one-process multi-GPU path, "
-                                    "not a scaling figure)"}
-        finally:
-            m.close()
+                    mm = rm.MultiRenderer([local] * 4, transport)
+                    ring.append(mm)
+                    mm.set_params(params)
+                    mm.set_scene(scene)
+                    outs.append(torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"))
+                    for _ in range(4):
+                        mm.render_device(outs[-1].data_ptr())
+                m = ring[0]
+                n_m = max(8, min(a.steps, 50))
+                t1 = time.perf_counter()
+                for _ in range(n_m):
+                    m.render_device(outs[0].data_ptr())
+                multi_ms = (time.perf_counter() - t1) / n_m * 1e3
+                one_equal = bool(torch.equal(outs[0], single))
+                # three frames in flight: three such objects take turns (rm_multi_enqueue_device / rm_multi_wait)
+                for o in outs:
+                    o.zero_()
+                n_p = 3 * max(4, min(a.steps, 60) // 3)
+                t1 = time.perf_counter()
+                for i in range(n_p):
+                    q = ring[i % 3]
+                    q.wait()
+                    q.enqueue_device(outs[i % 3].data_ptr())
+                for q in ring:
+                    q.wait()
+                piped_ms = (time.perf_counter() - t1) / n_p * 1e3
+                return {"transport": names[m.transport], "frame_ms": round(multi_ms, 4), "frame_equals_single_launch": one_equal,
+                        "frame_ms_three_in_flight": round(piped_ms, 4),
+                        "frames_in_flight_equal_single_launch": all(bool(torch.equal(o, single)) for o in outs)}
+            finally:
+                for mm in ring:
+                    mm.close()
+
+        native_multi = {"ranks": 4, "devices": [local] * 4}
+        native_multi.update(multi_leg(rm.MULTI_AUTO))
+        native_multi["gathered_by_copies"] = multi_leg(rm.MULTI_COPY)
+        native_multi["note"] = ("rm_multi_render_device / rm_multi_enqueue_device: the frame's 4-row bands dealt to four contexts of this one "
+                                "GPU, every rank storing its rows at their place in the caller's frame (no exchange step), and for comparison "
+                                "shares gathered and de-interleaved by copies on rank 0 (a functional rehearsal of the one-process multi-GPU "
+                                "path, not a scaling figure)")
     # ---- cold start: a fresh process uploads the scene and renders its first frame, with an empty cache directory
     # and again with what the first run left in it (compiled kernels, measured tile order)
     first = None

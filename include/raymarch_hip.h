@@ -182,6 +182,16 @@ int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, ui
  * black.  No counterpart in the reference (one GPU). */
 int rm_set_band_list(rm_context *ctx, const uint32_t *image_bands, uint32_t count);
 
+/* Where the device-buffer renders (rm_render_device, rm_enqueue_device, rm_enqueue_device_static) store their rows.
+ *   RM_ROWS_COMPACT   (default) a compact image of the call's bands, as described at rm_rows;
+ *   RM_ROWS_IN_FRAME  the buffers are whole frames (height * width * 4 floats / bytes) and every rendered row is stored
+ *                     at its own place in them; nothing else is written, rows of bands below the image not at all.
+ *                     Calls with different bands -- on contexts of different GPUs, into memory all of them can write --
+ *                     then fill one frame between them, with no gathering copy afterwards.
+ * The host-image calls are not affected.  No counterpart in the reference (one GPU). */
+typedef enum rm_row_placement { RM_ROWS_COMPACT = 0, RM_ROWS_IN_FRAME = 1 } rm_row_placement;
+int rm_set_row_placement(rm_context *ctx, int placement);
+
 /*
  * The same without waiting (the reference's render::GPU blocks in glGetTexImage, render.cpp:474;
  * these exist so that a caller can keep several frames in flight, e.g. two contexts on two
@@ -402,12 +412,19 @@ int rm_set_scene_from(rm_context *ctx, const rm_scene *scene);
  *              RM_MULTI_COPY   peer copies (hipMemcpy2DAsync between the devices' memories), which also serve a
  *                              device list that names a GPU more than once -- RCCL refuses two ranks on one
  *                              device -- so that the whole path can be exercised on a single GPU;
- *              RM_MULTI_AUTO   RCCL when n > 1 and all devices differ, copies otherwise.
+ *              RM_MULTI_DIRECT no exchange step: every rank's kernels store their rows at their place in the frame on
+ *                              rank 0's device (rm_set_row_placement on every rank; stores into a peer's memory,
+ *                              which need peer access from every device to the first) -- for rm_multi_render_device
+ *                              straight into the caller's buffer, which must then be memory of rank 0's device
+ *                              that the other devices can write (hipMalloc there); rank 0's stream only waits for
+ *                              the ranks' kernels.  Serves repeated devices too;
+ *              RM_MULTI_AUTO   direct stores where every device can access the first one's memory, else RCCL when all
+ *                              devices differ, else copies.
  * Calls on one rm_multi are serialised by the caller, like calls on a context.  The first frame of a configuration
  * renders rank after rank (each times its tiles); later frames run on all ranks at once.
  */
 typedef struct rm_multi rm_multi;
-typedef enum rm_multi_transport { RM_MULTI_AUTO = 0, RM_MULTI_RCCL = 1, RM_MULTI_COPY = 2 } rm_multi_transport;
+typedef enum rm_multi_transport { RM_MULTI_AUTO = 0, RM_MULTI_RCCL = 1, RM_MULTI_COPY = 2, RM_MULTI_DIRECT = 3 } rm_multi_transport;
 #define RM_MULTI_BAND_ROWS 4u
 int rm_multi_create(const int *devices, uint32_t n_devices, int transport, rm_multi **out);
 int rm_multi_destroy(rm_multi *m);
@@ -429,7 +446,7 @@ int rm_multi_enqueue_rgba8(rm_multi *m, uint8_t *host_image);
 int rm_multi_enqueue_device(rm_multi *m, uint8_t *device_rgba8);
 int rm_multi_wait(rm_multi *m);
 /* Rank r's context (settings such as rm_set_kernel_mode or rm_set_shading before the scene is set, counters after a
- * frame), the number of ranks, and the transport in use (RM_MULTI_RCCL or RM_MULTI_COPY). */
+ * frame), the number of ranks, and the transport in use (RM_MULTI_RCCL, RM_MULTI_COPY or RM_MULTI_DIRECT). */
 rm_context *rm_multi_context(rm_multi *m, uint32_t rank);
 uint32_t rm_multi_ranks(const rm_multi *m);
 int rm_multi_transport_in_use(const rm_multi *m);

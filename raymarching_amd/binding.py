@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(os.path.dirname(os.path
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_reserve", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_set_slot_stats", "rm_get_slot_stats", "rm_get_exact_tiles", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_set_row_placement", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_set_slot_stats", "rm_get_slot_stats", "rm_get_exact_tiles", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
     "rm_multi_create", "rm_multi_destroy", "rm_multi_set_params", "rm_multi_set_scene", "rm_multi_set_scene_from",
@@ -92,6 +92,7 @@ def lib():
     L.rm_static_scratch_bytes.restype = C.c_size_t
     L.rm_wait.argtypes = [vp]
     L.rm_set_band_list.argtypes = [vp, vp, C.c_uint32]
+    L.rm_set_row_placement.argtypes = [vp, C.c_int]
     L.rm_set_stream.argtypes = [vp, vp]
     L.rm_eval_sdf.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.rm_eval_sdf_both.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
@@ -287,6 +288,11 @@ class Renderer:
         arr = np.ascontiguousarray(image_bands if image_bands is not None else [], np.uint32)
         _check(lib().rm_set_band_list(self._h, arr.ctypes.data if len(arr) else None, len(arr)), "rm_set_band_list")
 
+    def set_row_placement(self, in_frame):
+        """in_frame: the device-buffer renders take whole frames and store every rendered row at its own place in them
+        (contexts with different bands then fill one frame between them); False: a compact image of the call's bands."""
+        _check(lib().rm_set_row_placement(self._h, 1 if in_frame else 0), "rm_set_row_placement")
+
     def wait(self):
         _check(lib().rm_wait(self._h), "rm_wait")
 
@@ -385,7 +391,7 @@ class _BorrowedRenderer(Renderer):
         self._h = None
 
 
-MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
+MULTI_AUTO, MULTI_RCCL, MULTI_COPY, MULTI_DIRECT = 0, 1, 2, 3
 
 
 class MultiRenderer:

@@ -190,6 +190,7 @@ struct rm_context {
     DeviceArray<uint32_t> d_band_list;
     std::vector<uint32_t> band_list_host;
     uint32_t band_list_size = 0;   // 0: bands are first_band + b * band_stride
+    bool rows_in_frame = false;    // rm_set_row_placement: device-buffer renders store every row at its place in a whole frame
     uint64_t band_list_serial = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
     PinnedWords h_tiles;   // staging of both
@@ -407,8 +408,9 @@ int ensure_tile_flags(rm_context *ctx, size_t tiles) {
 
 // static_samples: the device's static scratch (rm_enqueue_device_static) -- the call then allocates nothing: the sample
 // image goes there, tiles are never timed, and a configuration that would need a buffer the context does not hold is refused.
+// in_frame: the outputs are whole frames and every row goes to its own place in them (FrameView::rows_in_frame).
 int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool may_measure,
-                  rmdev::Sample *static_samples = nullptr) {
+                  rmdev::Sample *static_samples = nullptr, bool in_frame = false) {
     if (rows.band_rows == 0 || rows.band_count == 0 || rows.band_stride == 0)
         return fail(RM_ERR_INVALID, "rm_rows: band_rows, band_stride and band_count must be non-zero");
     RM_HIP(hipSetDevice(ctx->device));
@@ -419,6 +421,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
         fr.band_list = ctx->d_band_list.ptr;
     }
     fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
+    fr.rows_in_frame = in_frame ? 1u : 0u;
     const LaunchShape shape = launch_shape(ctx, fr, d_f32 || d_rgba8, static_samples != nullptr);
     const bool compiled = shape.compiled, fused = shape.fused, refill = shape.refill;
     const bool wide_runs = ctx->program.run_prims >= 64;
@@ -623,8 +626,8 @@ int finish_bands(rm_context *ctx) {
 }
 
 // Trace + resolve of the given bands into device buffers; synchronises the stream.
-int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8) {
-    if (int rc = enqueue_bands(ctx, rows, d_f32, d_rgba8, true)) return rc;
+int render_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned char *d_rgba8, bool in_frame = false) {
+    if (int rc = enqueue_bands(ctx, rows, d_f32, d_rgba8, true, nullptr, in_frame)) return rc;
     return finish_bands(ctx);
 }
 
@@ -959,13 +962,13 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
 int rm_render_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
     if (int rc = check_ready(ctx)) return rc;
     if (!rows) return fail(RM_ERR_INVALID, "rm_render_device: null rows");
-    return render_bands(ctx, *rows, device_f32, device_rgba8);
+    return render_bands(ctx, *rows, device_f32, device_rgba8, ctx->rows_in_frame);
 }
 
 int rm_enqueue_device(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
     if (int rc = check_ready(ctx)) return rc;
     if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_device: null rows");
-    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false);
+    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false, nullptr, ctx->rows_in_frame);
 }
 
 int rm_enqueue_device_static(rm_context *ctx, const rm_rows *rows, float *device_f32, uint8_t *device_rgba8) {
@@ -973,7 +976,14 @@ int rm_enqueue_device_static(rm_context *ctx, const rm_rows *rows, float *device
     if (!rows) return fail(RM_ERR_INVALID, "rm_enqueue_device_static: null rows");
     void *ptr = static_scratch(ctx->device);
     if (!ptr) return fail(RM_ERR_STATE, "rm_enqueue_device_static: no static scratch on device " + std::to_string(ctx->device));
-    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false, static_cast<rmdev::Sample *>(ptr));
+    return enqueue_bands(ctx, *rows, device_f32, device_rgba8, false, static_cast<rmdev::Sample *>(ptr), ctx->rows_in_frame);
+}
+
+int rm_set_row_placement(rm_context *ctx, int placement) {
+    if (!ctx) return fail(RM_ERR_INVALID, "null context");
+    if (placement != RM_ROWS_COMPACT && placement != RM_ROWS_IN_FRAME) return fail(RM_ERR_INVALID, "rm_set_row_placement: unknown placement");
+    ctx->rows_in_frame = placement == RM_ROWS_IN_FRAME;
+    return RM_OK;
 }
 
 size_t rm_static_scratch_bytes(void) { return kStaticScratchBytes; }

@@ -148,8 +148,20 @@ __device__ __forceinline__ V3 sample_colour(const Float4 *__restrict__ colors, S
     return v3(s.light * base.x, s.light * base.y, s.light * base.z);
 }
 
+// The output row at which row `ly` of the launch's band image is stored (FrameView::rows_in_frame): `ly` itself in a compact
+// band image, the row's place in the frame otherwise -- kNoOutputRow for a row of a band below the image.
+constexpr uint32_t kNoOutputRow = 0xffffffffu;
+__device__ __forceinline__ uint32_t output_row(const FrameView &fr, uint32_t ly) {
+    if (fr.rows_in_frame == 0u) return ly;
+    const uint32_t band = ly / fr.band_rows;
+    const uint32_t image_band = fr.band_list ? ((ConstIndex)fr.band_list)[band < fr.band_count ? band : fr.band_count - 1u]
+                                             : fr.first_band + band * fr.band_stride;
+    const uint32_t pi = image_band * fr.band_rows + (ly - band * fr.band_rows);
+    return pi < fr.height ? pi : kNoOutputRow;
+}
+
 // render.cpp:113-119 and the image writer's rule: pixel = total / (k * k), alpha 1; RGBA8 = round(clamp(c, 0, 1) * 255).
-// (x, y): pixel in the launch's compact band image of `width` pixels per row.
+// (x, y): pixel in the output image of `width` pixels per row (y from output_row).
 __device__ __forceinline__ void store_pixel(float tx, float ty, float tz, uint32_t k, uint32_t width, uint32_t x, uint32_t y,
                                             float *__restrict__ out_f32, unsigned char *__restrict__ out_rgba8) {
     const float n = (float)(k * k);

@@ -198,6 +198,11 @@ struct FrameView {
     // Which image band each band of the launch is (null: band b is first_band + b * band_stride): lets
     // a caller deal bands to GPUs by measured cost instead of cyclically.
     const uint32_t *band_list;
+    // Zero: pixels go to a compact image of the launch's bands (row b * band_rows + i of the output is row i of the
+    // launch's band b).  Nonzero: the outputs are whole frames of `height` rows and every rendered row is stored at its own
+    // place in them; rows of bands that lie below the image are not stored at all.  Several launches -- on several GPUs --
+    // then fill one frame between them without a copy.
+    uint32_t rows_in_frame;
     // Pixels straight from the trace kernel (either pointer may be null; both null: the kernel writes `samples` for
     // the resolve kernel instead).  Set only for kernels of one wave per workgroup and one sample per lane, and only
     // when the SSAA kernel divides the tile's 8 samples per side, so that a workgroup holds whole pixels.

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= fr.width || y >= rows) return;
+    const uint32_t out_y = output_row(fr, y);
+    if (out_y == kNoOutputRow) return;
     const uint32_t k = fr.kernel;
     const size_t sw = (size_t)fr.width * k;
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
             tz += c.z;
         }
     }
-    store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
+    store_pixel(tx, ty, tz, k, fr.width, x, out_y, out_f32, out_rgba8);
 }
 
 // ---- cell grid build -------------------------------------------------------------------------

@@ -123,8 +123,10 @@ int main(int argc, char **argv) {
     if (frames > 1) std::cout << "Render with GPU (later frames):\t" << render_s << "s per frame over " << frames - 1 << std::endl;
     std::cout << "Kernel compile:\t\t\t" << compile_s << "s" << std::endl;
     if (render::multi())
-        std::cout << "Devices:\t\t\t" << n_ranks << " ranks, shares gathered by "
-                  << (rm_multi_transport_in_use(render::multi()) == RM_MULTI_RCCL ? "RCCL send/recv" : "peer copies") << std::endl;
+        std::cout << "Devices:\t\t\t" << n_ranks << " ranks, "
+                  << (rm_multi_transport_in_use(render::multi()) == RM_MULTI_DIRECT ? "rows stored straight into the first device's frame"
+                      : rm_multi_transport_in_use(render::multi()) == RM_MULTI_RCCL ? "shares gathered by RCCL send/recv" : "shares gathered by peer copies")
+                  << std::endl;
     std::cout << "Trace kernel:\t\t\t" << c.kernel_ms * 1e-3 << "s (" << (c.compiled_kernel ? "compiled for the scene" : "record walker")
               << "), resolve " << c.resolve_ms * 1e-3 << "s" << std::endl;
     std::cout << "Throughput:\t\t\t" << rays / render_s / 1e6 << " Mrays/s (" << (uint64_t)rays << " rays per frame, " << frames

@@ -7,7 +7,10 @@
 // gives every rank a statistically equal share with all shares the same size -- and the shares are gathered on rank
 // 0's device: grouped ncclSend / ncclRecv (RCCL over xGMI: every peer has its own link to rank 0) followed by a
 // de-interleaving 2-D copy per rank, or, where the device list repeats a device (RCCL refuses that), 2-D peer copies
-// that de-interleave on the way.  Built on the public C ABI only: a rank is an ordinary context.
+// that de-interleave on the way.  Or no exchange step at all (RM_MULTI_DIRECT): every rank's kernels store their rows
+// at their place in the frame on rank 0's device -- stores to a peer's memory travel over the rank's own xGMI link to
+// rank 0 as the pixels are finished -- and rank 0's stream only waits for the ranks' kernels.
+// Built on the public C ABI only: a rank is an ordinary context.
 #include "../../include/raymarch_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -136,11 +139,13 @@ int plan(rm_multi *m) {
     m->band_bytes = (size_t)RM_MULTI_BAND_ROWS * p.width * 4u;
     m->shard_bytes = (size_t)m->bands_per_rank * m->band_bytes;
     const size_t frame_bytes = (size_t)p.width * p.height * 4u;
-    if (m->shard_bytes <= m->shard_capacity && frame_bytes <= m->frame_bytes) return RM_OK;
+    const bool shards = m->transport != RM_MULTI_DIRECT;   // direct stores need the frame only
+    if ((!shards || m->shard_bytes <= m->shard_capacity) && frame_bytes <= m->frame_bytes) return RM_OK;
     release_buffers(m);
     RM_MHIP(hipSetDevice(m->ranks[0].device));
     RM_MHIP(hipMalloc(reinterpret_cast<void **>(&m->frame), frame_bytes));
     m->frame_bytes = frame_bytes;
+    if (!shards) return RM_OK;
     if (m->transport == RM_MULTI_RCCL) {
         m->stack_bytes = m->shard_bytes * n;
         RM_MHIP(hipMalloc(reinterpret_cast<void **>(&m->stack), m->stack_bytes));
@@ -177,24 +182,30 @@ int scatter_share(rm_multi *m, uint32_t r, const unsigned char *src, hipStream_t
     return RM_OK;
 }
 
-int render_frame(rm_multi *m) {
+// Queues the frame on every rank and its exchange on rank 0's stream.  `direct`: where the ranks' kernels store the frame
+// when the transport is RM_MULTI_DIRECT (on rank 0's device; null: the object's own frame).  Afterwards the frame lies
+// there, or with the other transports in the object's own frame.
+int render_frame(rm_multi *m, unsigned char *direct) {
     if (!m->have_params) return rm_internal_fail(RM_ERR_STATE, "rm_multi_set_params has not been called");
     if (!m->have_scene) return rm_internal_fail(RM_ERR_STATE, "rm_multi_set_scene has not been called");
     if (int rc = plan(m)) return rc;
     const uint32_t n = (uint32_t)m->ranks.size();
     hipStream_t stream0 = static_cast<hipStream_t>(rm_stream(m->ranks[0].ctx));
+    const bool in_place = m->transport == RM_MULTI_DIRECT;
+    if (in_place && !direct) direct = m->frame;
     // ---- every rank renders its bands
     for (uint32_t r = 0; r < n; r++) {
         Rank &k = m->ranks[r];
         const rm_rows rows = { RM_MULTI_BAND_ROWS, r, n, m->bands_per_rank };
+        unsigned char *const out = in_place ? direct : k.shard;
         if (!k.ordered) {
             // the first frame of a configuration: synchronous, so that the context times its tiles (or reads their order
             // from the cache directory); queued frames never measure
-            if (int rc = rm_render_device(k.ctx, &rows, nullptr, k.shard)) return rc;
+            if (int rc = rm_render_device(k.ctx, &rows, nullptr, out)) return rc;
             k.ordered = true;
             k.queued = false;
         } else {
-            if (int rc = rm_enqueue_device(k.ctx, &rows, nullptr, k.shard)) return rc;
+            if (int rc = rm_enqueue_device(k.ctx, &rows, nullptr, out)) return rc;
             k.queued = true;
         }
         RM_MHIP(hipSetDevice(k.device));
@@ -202,7 +213,10 @@ int render_frame(rm_multi *m) {
     }
     // ---- the exchange: shares to rank 0's device, de-interleaved into the frame
     RM_MHIP(hipSetDevice(m->ranks[0].device));
-    if (m->transport == RM_MULTI_RCCL) {
+    if (in_place) {
+        // the rows are where they belong once the ranks' kernels have ended
+        for (uint32_t r = 1; r < n; r++) RM_MHIP(hipStreamWaitEvent(stream0, m->ranks[r].rendered, 0));
+    } else if (m->transport == RM_MULTI_RCCL) {
         const Rccl &nc = rccl();
         RM_NCCL(nc.GroupStart());
         for (uint32_t r = 1; r < n; r++) {
@@ -251,12 +265,21 @@ int rm_multi_create(const int *devices, uint32_t n_devices, int transport, rm_mu
     if (!out) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_create: null output pointer");
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64u) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_create: 1 to 64 devices");
-    if (transport != RM_MULTI_AUTO && transport != RM_MULTI_RCCL && transport != RM_MULTI_COPY)
+    if (transport != RM_MULTI_AUTO && transport != RM_MULTI_RCCL && transport != RM_MULTI_COPY && transport != RM_MULTI_DIRECT)
         return rm_internal_fail(RM_ERR_INVALID, "rm_multi_create: unknown transport");
     const bool distinct = std::set<int>(devices, devices + n_devices).size() == n_devices;
     if (transport == RM_MULTI_RCCL && !distinct)
         return rm_internal_fail(RM_ERR_INVALID, "rm_multi_create: RCCL takes one rank per device; this list names a device twice (use RM_MULTI_COPY)");
-    if (transport == RM_MULTI_AUTO) transport = (distinct && n_devices > 1u) ? RM_MULTI_RCCL : RM_MULTI_COPY;
+    if (transport == RM_MULTI_AUTO) {
+        // direct stores wherever every rank's device can write rank 0's memory; RCCL otherwise
+        bool peers = true;
+        for (uint32_t r = 1; r < n_devices && peers; r++) {
+            int can = 0;
+            if (devices[r] != devices[0] && (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) != hipSuccess || !can)) peers = false;
+        }
+        (void)hipGetLastError();
+        transport = peers ? RM_MULTI_DIRECT : (distinct ? RM_MULTI_RCCL : RM_MULTI_COPY);
+    }
     if (transport == RM_MULTI_RCCL && n_devices == 1u) transport = RM_MULTI_COPY;   // nothing to exchange
     rm_multi *m = new (std::nothrow) rm_multi();
     if (!m) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_create: out of host memory");
@@ -280,7 +303,26 @@ int rm_multi_create(const int *devices, uint32_t n_devices, int transport, rm_mu
         rm_internal_fail(RM_ERR_HIP, "rm_multi_create: hipEventCreate failed on device " + std::to_string(devices[0]));
         return undo(RM_ERR_HIP);
     }
-    if (transport == RM_MULTI_COPY) {
+    if (transport == RM_MULTI_DIRECT) {
+        // every rank's kernels write the frame on rank 0's device
+        for (uint32_t r = 0; r < n_devices; r++) {
+            if (int rc = rm_set_row_placement(m->ranks[r].ctx, RM_ROWS_IN_FRAME)) return undo(rc);
+            if (devices[r] == devices[0]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) != hipSuccess || !can) {
+                rm_internal_fail(RM_ERR_HIP, "rm_multi_create: device " + std::to_string(devices[r]) + " cannot write device " +
+                                                 std::to_string(devices[0]) + "'s memory (no peer access)");
+                return undo(RM_ERR_HIP);
+            }
+            hipError_t e = hipSetDevice(devices[r]);
+            if (e == hipSuccess) e = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                rm_internal_fail(RM_ERR_HIP, std::string("rm_multi_create: hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                return undo(RM_ERR_HIP);
+            }
+            (void)hipGetLastError();
+        }
+    } else if (transport == RM_MULTI_COPY) {
         // rank 0's device reads the other devices' memory in the gathering copies
         for (uint32_t r = 1; r < n_devices; r++) {
             if (devices[r] == devices[0]) continue;
@@ -378,10 +420,12 @@ int rm_multi_set_scene_from(rm_multi *m, const rm_scene *scene) {
 int rm_multi_enqueue_device(rm_multi *m, uint8_t *device_rgba8) {
     if (!m || !device_rgba8) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_enqueue_device: null argument");
     if (m->in_flight) return rm_internal_fail(RM_ERR_STATE, "rm_multi_enqueue_device: a frame is in flight (rm_multi_wait first)");
-    if (int rc = render_frame(m)) return rc;
+    if (int rc = render_frame(m, device_rgba8)) return rc;
     hipStream_t stream0 = static_cast<hipStream_t>(rm_stream(m->ranks[0].ctx));
-    RM_MHIP(hipMemcpyAsync(device_rgba8, m->frame, (size_t)m->params.width * m->params.height * 4u, hipMemcpyDeviceToDevice, stream0));
-    RM_MHIP(hipEventRecord(m->gathered, stream0));
+    if (m->transport != RM_MULTI_DIRECT) {
+        RM_MHIP(hipMemcpyAsync(device_rgba8, m->frame, (size_t)m->params.width * m->params.height * 4u, hipMemcpyDeviceToDevice, stream0));
+        RM_MHIP(hipEventRecord(m->gathered, stream0));
+    }
     m->in_flight = true;
     return RM_OK;
 }
@@ -389,7 +433,7 @@ int rm_multi_enqueue_device(rm_multi *m, uint8_t *device_rgba8) {
 int rm_multi_enqueue_rgba8(rm_multi *m, uint8_t *host_image) {
     if (!m || !host_image) return rm_internal_fail(RM_ERR_INVALID, "rm_multi_enqueue_rgba8: null argument");
     if (m->in_flight) return rm_internal_fail(RM_ERR_STATE, "rm_multi_enqueue_rgba8: a frame is in flight (rm_multi_wait first)");
-    if (int rc = render_frame(m)) return rc;
+    if (int rc = render_frame(m, nullptr)) return rc;
     hipStream_t stream0 = static_cast<hipStream_t>(rm_stream(m->ranks[0].ctx));
     RM_MHIP(hipMemcpyAsync(host_image, m->frame, (size_t)m->params.width * m->params.height * 4u, hipMemcpyDeviceToHost, stream0));
     RM_MHIP(hipEventRecord(m->gathered, stream0));

@@ -32,7 +32,7 @@ void GPU(unsigned char *image);
 namespace setup {
 // Extension: the devices the frame is rendered on, before context().  One device (the default: device 0) is the
 // reference's case; with more, context() creates one rank per entry and GPU() shards every frame over them by row
-// bands and gathers it (rm_multi_*: RCCL between distinct devices).
+// bands and gathers it (rm_multi_*: direct stores into the first device's frame, or RCCL where the devices have no peer access).
 void devices(const int *device_ids, unsigned count);
 void context(void);
 void shaders(void);

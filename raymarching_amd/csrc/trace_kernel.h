@@ -493,7 +493,8 @@ __device__ __forceinline__ void trace_body(const SceneView &sc, const FrameView 
                     tz += c[2];
                 }
             }
-            store_pixel(tx, ty, tz, k, fr.width, gx / k, gy / k, fr.pixels_f32, fr.pixels_rgba8);
+            const uint32_t out_y = output_row(fr, gy / k);
+            if (out_y != kNoOutputRow) store_pixel(tx, ty, tz, k, fr.width, gx / k, out_y, fr.pixels_f32, fr.pixels_rgba8);
         }
     }
     if (fr.tile_cost && lane == 0u) fr.tile_cost[tile] = (uint32_t)(wall_clock64() - started);
@@ -548,6 +549,8 @@ __device__ __forceinline__ void trace_exact_body(const SceneView &sc, const Fram
     for (uint32_t q = 0; q < (uint32_t)kPts; ++q) {
         const uint32_t x = (blockIdx.x * (uint32_t)kPts + q) * tile_side + threadIdx.x % tile_side, y = blockIdx.y * tile_side + threadIdx.x / tile_side;
         if (x >= fr.width || y >= rows) continue;
+        const uint32_t out_y = output_row(fr, y);
+        if (out_y == kNoOutputRow) continue;
         float tx = 0.0f, ty = 0.0f, tz = 0.0f;
         for (uint32_t i = 0; i < k; ++i) {
             for (uint32_t j = 0; j < k; ++j) {
@@ -557,7 +560,7 @@ __device__ __forceinline__ void trace_exact_body(const SceneView &sc, const Fram
                 tz += c.z;
             }
         }
-        store_pixel(tx, ty, tz, k, fr.width, x, y, out_f32, out_rgba8);
+        store_pixel(tx, ty, tz, k, fr.width, x, out_y, out_f32, out_rgba8);
     }
 }
 

@@ -32,8 +32,8 @@ def test_driver_report_and_frame(oracle, tmp_path):
 
 
 def test_driver_shards_a_frame_over_listed_devices(oracle, tmp_path):
-    """raymarch --devices 0,0,0: render::setup::devices + render::GPU over three ranks on this one GPU (shares gathered by
-    copies); the frame is the one-device frame."""
+    """raymarch --devices 0,0,0: render::setup::devices + render::GPU over three ranks on this one GPU (every rank stores
+    its rows straight into the first device's frame); the frame is the one-device frame."""
     if not os.path.isfile(DRIVER):
         pytest.skip("raymarching_amd/raymarch has not been built (make -C raymarching_amd/csrc)")
     raw = tmp_path / "out.rgba"
@@ -41,7 +41,7 @@ def test_driver_shards_a_frame_over_listed_devices(oracle, tmp_path):
            "--frames", "3", "--raw", str(raw), "--out", ""]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "[Error]" not in out.stdout and "3 ranks, shares gathered by peer copies" in out.stdout, out.stdout
+    assert "[Error]" not in out.stdout and "3 ranks, rows stored straight into the first device's frame" in out.stdout, out.stdout
     img = np.fromfile(raw, dtype=np.uint8).reshape(90, 128, 4)
     ref, _ = oracle.Scene(scene_path("menger2.txt")).render(oracle.default_params(width=128, height=90, kernel=2))
     assert np.array_equal(img, oracle.quantize(ref))
