@@ -236,7 +236,7 @@ def main():
     if a.balance:
         # dealing by cost needs the tiles' measured durations; a tile order read from the cache directory comes without them
         rm.set_kernel_cache_dir(None)
-    rs, set_scene_s = [], 0.0
+    rs, set_scene_s, compiled_by = [], 0.0, None
     for f in range(F):
         rr = rm.Renderer(local)
         rr.set_params(params)
@@ -247,6 +247,7 @@ def main():
         rr.set_scene(scene)
         if f == 0:
             set_scene_s = time.perf_counter() - t0   # later contexts find the kernels in the code cache
+            compiled_by = rm.kernel_compiler()
         rs.append(rr)
     r = rs[0]
 
@@ -595,12 +596,16 @@ def main():
         d = tempfile.mkdtemp(prefix="rm_bench_cache_")
         try:
             runs = []
-            for _ in range(2):
+            for leg in range(2):
+                # the compiler keeps a cache of its own under the user's cache directory (this process has just compiled the
+                # same kernels): off for the run that is to show a compile
+                env = dict(os.environ, AMD_COMGR_CACHE="0") if leg == 0 else None
                 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_frame.py"), a.workload, d],
-                                     capture_output=True, text=True, timeout=300)
+                                     capture_output=True, text=True, timeout=300, env=env)
                 runs.append(json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": out.stderr[-300:]})
             first = {"empty_cache": runs[0], "warm_cache": runs[1],
-                     "note": "tools/first_frame.py in a fresh process: rm_set_scene, then three rm_render_rgba8 into page-locked memory"}
+                     "note": "tools/first_frame.py in a fresh process: rm_set_scene, then three rm_render_rgba8 into page-locked memory "
+                             "(empty_cache: no code object anywhere, the compiler's own cache off too)"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
@@ -633,7 +638,7 @@ def main():
                                    "value counts the frame's nominal rays, rays_cast_per_frame those marched") if a.shading == "coloured"
                                   else "every sample (the reference's full work)",
                        "evaluator": a.evaluator, "kernel_mode": a.kernel_mode,
-                       "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1),
+                       "set_scene_s": round(set_scene_s, 3), "kernel_compile_ms": round(cnt["compile_ms"], 1), "kernels_compiled_by": compiled_by,
                        "frames_in_flight": F, "frames_per_gather": G, "untimed_frames_before_warmup": pre_roll,
                        "sharding": ("single launch" + (", sent through a one-rank RCCL gather" if group else "")) if world == 1 else f"row bands of {a.band_rows} over {world} ranks, " + ("dealt by measured cost" if band_lists is not None else "cyclic") + ", RCCL gather of RGBA8 to rank 0"},
             "roofline": {

@@ -337,6 +337,14 @@ int rm_set_lane_refill(rm_context *ctx, uint32_t tile_w_log2, uint32_t tile_h_lo
 int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int counting, char *buffer, size_t capacity,
                      size_t *length);
 int rm_kernel_source_compiles(const char *source);
+/* How this process last obtained the code object of a scene's kernels (a text owned by the library, valid until the calling
+ * thread's next call of this function): "rm_jit (a process of its own): <path>" -- the library compiles with the program
+ * rm_jit that is installed beside it, a process of its own linked against the ROCm release the library was built with, so
+ * that the kernels do not depend on which other copy of hiprtc the calling process has loaded (PyTorch bundles an older
+ * one under the same SONAME; its kernels measure 3-6 % slower); "hiprtc in this process" where that program is missing
+ * or cannot run ($RM_JIT_HELPER names another program; "" or "off" keeps the compiler in the process); "none: code object
+ * from the cache directory"; "none yet".  No counterpart in the reference, whose driver compiles its shader itself. */
+const char *rm_kernel_compiler(void);
 /* Process-wide: where compiled code objects and measured tile orders are kept so that later processes load them
  * instead of compiling (0.3-1.3 s per scene) or timing the tiles again.  ON BY DEFAULT: without this call the library
  * uses $RM_KERNEL_CACHE_DIR, else $XDG_CACHE_HOME/raymarch_hip, $HOME/.cache/raymarch_hip, /tmp/raymarch_hip-<uid>

@@ -191,6 +191,7 @@ struct rm_context {
     std::vector<uint32_t> band_list_host;
     uint32_t band_list_size = 0;   // 0: bands are first_band + b * band_stride
     bool rows_in_frame = false;    // rm_set_row_placement: device-buffer renders store every row at its place in a whole frame
+    bool module_places_rows = false;   // the scene's kernels were compiled with RM_PLACE_ROWS
     uint64_t band_list_serial = 0;   // shape of the tile grid d_tile_cost holds
     DeviceArray<uint32_t> d_tile_order, d_tile_cost;
     PinnedWords h_tiles;   // staging of both
@@ -396,6 +397,41 @@ int preload_tile_order(rm_context *ctx) {
     return RM_OK;
 }
 
+// Compiles and loads the kernels of the context's scene (RM_KERNEL_COMPILED; otherwise only unloads the last scene's) and
+// launches each of them once.  A context that places rows (rm_set_row_placement) compiles them with RM_PLACE_ROWS.
+int load_scene_module(rm_context *ctx) {
+    ctx->module.unload();
+    ctx->counting_module.unload();
+    ctx->module_places_rows = false;
+    if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
+        std::string log;
+        const std::string source = std::string(ctx->rows_in_frame ? "#define RM_PLACE_ROWS 1\n" : "") +
+                                   rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false, ctx->refill_w_log2 != 0u);
+        if (!rmdev::compile_scene_module(source, kCompiledPts, ctx->module, log))
+            return fail(RM_ERR_HIP, "compiling the scene's kernels failed: " + log);
+        ctx->module_places_rows = ctx->rows_in_frame;
+    }
+    if (ctx->module.loaded()) {
+        // The first launch of a freshly loaded kernel costs milliseconds (code upload, queue set-up): one pixel now, where
+        // the reference compiles its shader, instead of inside the first frame.
+        rmdev::FrameView fr{};
+        fr.width = fr.height = fr.kernel = 1u;
+        fr.iterations = 1;
+        fr.surface_eps = fr.offset_eps = 1e-3f;
+        fr.band_rows = fr.band_stride = fr.band_count = 1u;
+        // into a buffer of the context's own: the GPU's static scratch may hold another context's frame in flight
+        RM_HIP(ctx->d_warm.reserve(1024));   // (the word at 512 counts the tiles the exact kernel renders: rm_get_exact_tiles)
+        unsigned char *const spare = ctx->d_warm.ptr;
+        RM_HIP(hipMemsetAsync(spare, 0, 1024, ctx->stream));
+        fr.tile_flags = reinterpret_cast<uint32_t *>(spare + 384);   // (zero: the exact kernel finds nothing to do, but has been launched once)
+        RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
+        RM_HIP(rmdev::launch_trace_exact_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
+        RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RM_OK;
+}
+
 // The words through which a scene's optimistic kernel asks for tiles to be rendered again (FrameView::tile_flags): at least
 // `tiles` of them, zero.  The kernels leave them zero, so they are cleared only when the buffer is new.
 int ensure_tile_flags(rm_context *ctx, size_t tiles) {
@@ -422,6 +458,7 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     }
     fr.skip_unlit = ctx->shading == RM_SHADE_COLOURED ? 1u : 0u;
     fr.rows_in_frame = in_frame ? 1u : 0u;
+    if (in_frame && ctx->module.loaded() && !ctx->module_places_rows) return fail(RM_ERR_STATE, "the scene's kernels were compiled without row placement");
     const LaunchShape shape = launch_shape(ctx, fr, d_f32 || d_rgba8, static_samples != nullptr);
     const bool compiled = shape.compiled, fused = shape.fused, refill = shape.refill;
     const bool wide_runs = ctx->program.run_prims >= 64;
@@ -491,7 +528,8 @@ int enqueue_bands(rm_context *ctx, const rm_rows &rows, float *d_f32, unsigned c
     }
     if (compiled && ctx->counting && !ctx->counting_module.loaded()) {
         std::string log;
-        if (!rmdev::compile_scene_module(rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true, ctx->refill_w_log2 != 0u), kCompiledPts,
+        if (!rmdev::compile_scene_module(std::string(ctx->rows_in_frame ? "#define RM_PLACE_ROWS 1\n" : "") +
+                                             rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, true, ctx->refill_w_log2 != 0u), kCompiledPts,
                                          ctx->counting_module, log))
             return fail(RM_ERR_HIP, "compiling the scene's counting kernel failed: " + log);
     }
@@ -914,15 +952,10 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
         const uint64_t digest[3] = { d0, d1, total };
         ctx->scene_fingerprint.assign(reinterpret_cast<const char *>(digest), sizeof digest);
     }
-    ctx->module.unload();
-    ctx->counting_module.unload();
-    if (ctx->kernel_mode == RM_KERNEL_COMPILED) {
-        std::string log;
-        const std::string source = rmdev::generate_scene_source(ctx->program, kCompiledPts, kCompiledWaves, false, ctx->refill_w_log2 != 0u);
-        if (!rmdev::compile_scene_module(source, kCompiledPts, ctx->module, log)) {
-            ctx->have_scene = false;
-            return fail(RM_ERR_HIP, "rm_set_scene: compiling the scene's kernels failed: " + log);
-        }
+    ctx->scene.camera_sd_known = 0u;
+    if (int rc = load_scene_module(ctx)) {
+        ctx->have_scene = false;
+        return rc;
     }
     ctx->have_scene = true;
     // the one evaluation all camera rays share (trace_kernel.h: march, first_sd), with the kernels just set up
@@ -937,24 +970,6 @@ int rm_set_scene(rm_context *ctx, const rm_node *nodes, uint32_t n_nodes, const 
             ctx->scene.camera_sd = sd_march;
             ctx->scene.camera_sd_known = 1u;
         }
-    }
-    if (ctx->module.loaded()) {
-        // The first launch of a freshly loaded kernel costs milliseconds (code upload, queue set-up): one pixel now, where
-        // the reference compiles its shader, instead of inside the first frame.
-        rmdev::FrameView fr{};
-        fr.width = fr.height = fr.kernel = 1u;
-        fr.iterations = 1;
-        fr.surface_eps = fr.offset_eps = 1e-3f;
-        fr.band_rows = fr.band_stride = fr.band_count = 1u;
-        // into a buffer of the context's own: the GPU's static scratch may hold another context's frame in flight
-        RM_HIP(ctx->d_warm.reserve(1024));   // (the word at 512 counts the tiles the exact kernel renders: rm_get_exact_tiles)
-        unsigned char *const spare = ctx->d_warm.ptr;
-        RM_HIP(hipMemsetAsync(spare, 0, 1024, ctx->stream));
-        fr.tile_flags = reinterpret_cast<uint32_t *>(spare + 384);   // (zero: the exact kernel finds nothing to do, but has been launched once)
-        RM_HIP(rmdev::launch_trace_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, ctx->stream));
-        RM_HIP(rmdev::launch_trace_exact_module(ctx->module, ctx->scene, fr, 1u, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
-        RM_HIP(rmdev::launch_resolve(fr, ctx->scene.colors, reinterpret_cast<rmdev::Sample *>(spare), nullptr, spare + 256, ctx->stream));
-        RM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return preload_tile_order(ctx);
 }
@@ -983,6 +998,15 @@ int rm_set_row_placement(rm_context *ctx, int placement) {
     if (!ctx) return fail(RM_ERR_INVALID, "null context");
     if (placement != RM_ROWS_COMPACT && placement != RM_ROWS_IN_FRAME) return fail(RM_ERR_INVALID, "rm_set_row_placement: unknown placement");
     ctx->rows_in_frame = placement == RM_ROWS_IN_FRAME;
+    // kernels compiled for the scene before the context placed rows do not know how to: once more, with the switch
+    if (ctx->rows_in_frame && ctx->have_scene && ctx->module.loaded() && !ctx->module_places_rows) {
+        RM_HIP(hipSetDevice(ctx->device));
+        RM_HIP(hipStreamSynchronize(ctx->stream));
+        if (int rc = load_scene_module(ctx)) {
+            ctx->have_scene = false;
+            return rc;
+        }
+    }
     return RM_OK;
 }
 
@@ -1139,6 +1163,12 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
 int rm_set_kernel_cache_dir(const char *directory) {
     rmdev::set_kernel_cache_dir(directory);
     return RM_OK;
+}
+
+const char *rm_kernel_compiler(void) {
+    static thread_local std::string text;
+    text = rmdev::kernel_compiler_used();
+    return text.c_str();
 }
 
 int rm_kernel_source_compiles(const char *source) {

@@ -151,13 +151,23 @@ __device__ __forceinline__ V3 sample_colour(const Float4 *__restrict__ colors, S
 // The output row at which row `ly` of the launch's band image is stored (FrameView::rows_in_frame): `ly` itself in a compact
 // band image, the row's place in the frame otherwise -- kNoOutputRow for a row of a band below the image.
 constexpr uint32_t kNoOutputRow = 0xffffffffu;
-__device__ __forceinline__ uint32_t output_row(const FrameView &fr, uint32_t ly) {
+__device__ __forceinline__ uint32_t placed_row(const FrameView &fr, uint32_t ly) {
     if (fr.rows_in_frame == 0u) return ly;
     const uint32_t band = ly / fr.band_rows;
     const uint32_t image_band = fr.band_list ? ((ConstIndex)fr.band_list)[band < fr.band_count ? band : fr.band_count - 1u]
                                              : fr.first_band + band * fr.band_stride;
     const uint32_t pi = image_band * fr.band_rows + (ly - band * fr.band_rows);
     return pi < fr.height ? pi : kNoOutputRow;
+}
+// The same for the kernels generated for a scene, which honour FrameView::rows_in_frame only when they are compiled with
+// RM_PLACE_ROWS (a context that places rows compiles its kernels so): the band plan's words kept until the pixels are
+// stored cost the 1024-object scene's kernel three spilled registers and 1 % of its time, and most contexts never place rows.
+__device__ __forceinline__ uint32_t output_row(const FrameView &fr, uint32_t ly) {
+#ifdef RM_PLACE_ROWS
+    return placed_row(fr, ly);
+#else
+    return ly;
+#endif
 }
 
 // render.cpp:113-119 and the image writer's rule: pixel = total / (k * k), alpha 1; RGBA8 = round(clamp(c, 0, 1) * 255).

@@ -7,8 +7,12 @@
 #include <hip/hiprtc.h>
 
 #include <dirent.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -84,11 +88,96 @@ std::vector<std::string> extra_options() {
     return out;
 }
 
+// ---- the compiler in a process of its own ---------------------------------------------------------
+// rm_jit (jit_helper.cpp), beside this library: $RM_JIT_HELPER names another program, "" or "off" keeps the compiler in
+// this process.  "" if there is none.
+extern "C" char **environ;
+
+std::string find_helper() {
+    if (const char *env = std::getenv("RM_JIT_HELPER")) {
+        const std::string v = env;
+        if (v.empty() || v == "off") return "";
+        return access(v.c_str(), X_OK) == 0 ? v : "";
+    }
+    Dl_info info{};
+    if (!dladdr(reinterpret_cast<const void *>(&find_helper), &info) || !info.dli_fname) return "";
+    std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/rm_jit";
+    return access(path.c_str(), X_OK) == 0 ? path : "";
+}
+
+const std::string &helper_path() {
+    static const std::string path = find_helper();
+    return path;
+}
+
+std::string g_compiler_used = "none yet";   // how this process last obtained a code object (kernel_compiler_used)
+
+bool read_whole_file(const std::string &path, std::vector<char> &out) {
+    std::FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    const bool ok = !std::ferror(f);
+    std::fclose(f);
+    return ok;
+}
+
+// Compiles `source` with the helper program.  1: `code` holds the code object; 0: the compiler refused the source (`log`);
+// -1: the helper could not be used (the caller compiles in this process).
+int compile_with_helper(const std::string &source, const std::vector<const char *> &options, std::vector<char> &code, std::string &log) {
+    const std::string &helper = helper_path();
+    if (helper.empty()) return -1;
+    const char *tmp = std::getenv("TMPDIR");
+    std::string src_path = std::string(tmp && *tmp ? tmp : "/tmp") + "/rm_jit_XXXXXX";
+    const int fd = mkstemp(&src_path[0]);   // 0600, a name nobody can guess
+    if (fd < 0) return -1;
+    const std::string out_path = src_path + ".bin", log_path = out_path + ".log";
+    auto cleanup = [&] {
+        (void)unlink(src_path.c_str());
+        (void)unlink(out_path.c_str());
+        (void)unlink(log_path.c_str());
+    };
+    size_t written = 0;
+    while (written < source.size()) {
+        const ssize_t n = write(fd, source.data() + written, source.size() - written);
+        if (n <= 0) break;
+        written += (size_t)n;
+    }
+    (void)close(fd);
+    if (written != source.size()) { cleanup(); return -1; }
+    std::vector<char *> argv = { const_cast<char *>(helper.c_str()), const_cast<char *>(src_path.c_str()), const_cast<char *>(out_path.c_str()) };
+    for (const char *o : options) argv.push_back(const_cast<char *>(o));
+    argv.push_back(nullptr);
+    pid_t pid = 0;
+    if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) != 0) { cleanup(); return -1; }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0) {
+        if (errno != EINTR) { cleanup(); return -1; }
+    }
+    int result = -1;
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+        code.clear();
+        if (read_whole_file(out_path, code) && !code.empty()) result = 1;
+    } else if (WIFEXITED(status) && WEXITSTATUS(status) == 2) {
+        std::vector<char> text;
+        if (read_whole_file(log_path, text)) {
+            log.assign(text.begin(), text.end());
+            result = 0;
+        }
+    }
+    cleanup();
+    return result;
+}
+
 // FNV-1a over the source and the embedded headers: names a code object file.  The file also holds
 // the full key text, compared on load, so a hash collision costs a recompile, never a wrong kernel.
 std::string cache_key_text(const std::string &source) {
     std::string key = source;
     for (const std::string &o : extra_options()) key += "\n//@option " + o;
+    if (!helper_path().empty()) key += "\n//@compiler rm_jit";   // (objects this process's own hiprtc made are kept apart)
     for (unsigned i = 0; i < kEmbeddedHeaderCount; i++) {
         key += "\n//@";
         key += kEmbeddedHeaders[i].name;
@@ -184,6 +273,24 @@ void store_to_disk(const std::string &source, const std::vector<char> &code) {
 }
 
 CodeObject build_code_object(const std::string &source, std::string &log) {
+    std::vector<const char *> options = { "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+                                          "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt" };
+    const std::vector<std::string> extra = extra_options();
+    for (const std::string &o : extra) options.push_back(o.c_str());
+    {
+        auto code = std::make_shared<std::vector<char>>();
+        const int by_helper = compile_with_helper(source, options, *code, log);
+        if (by_helper == 0) return nullptr;
+        if (by_helper == 1) {
+            std::lock_guard<std::mutex> hold(g_cache_lock);
+            g_compiler_used = "rm_jit (a process of its own): " + helper_path();
+            return code;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> hold(g_cache_lock);
+        g_compiler_used = "hiprtc in this process";
+    }
     std::vector<const char *> texts, names;
     for (unsigned i = 0; i < kEmbeddedHeaderCount; i++) {
         texts.push_back(kEmbeddedHeaders[i].text);
@@ -195,10 +302,6 @@ CodeObject build_code_object(const std::string &source, std::string &log) {
         log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
         return nullptr;
     }
-    std::vector<const char *> options = { "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
-                                          "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt" };
-    const std::vector<std::string> extra = extra_options();
-    for (const std::string &o : extra) options.push_back(o.c_str());
     r = hiprtcCompileProgram(prog, (int)options.size(), options.data());
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -222,6 +325,11 @@ CodeObject build_code_object(const std::string &source, std::string &log) {
 }
 
 }  // namespace
+
+std::string kernel_compiler_used() {
+    std::lock_guard<std::mutex> hold(g_cache_lock);
+    return g_compiler_used;
+}
 
 void SceneModule::unload() {
     if (module) (void)hipModuleUnload(module);
@@ -293,6 +401,10 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
     if (!code) {
         const auto t0 = std::chrono::steady_clock::now();
         code = load_from_disk(source);
+        if (code) {
+            std::lock_guard<std::mutex> hold(g_cache_lock);
+            g_compiler_used = "none: code object from the cache directory";
+        }
         if (!code) {
             code = build_code_object(source, log);
             if (!code) return false;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrameView fr, const 
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= fr.width || y >= rows) return;
-    const uint32_t out_y = output_row(fr, y);
+    const uint32_t out_y = placed_row(fr, y);
     if (out_y == kNoOutputRow) return;
     const uint32_t k = fr.kernel;
     const size_t sw = (size_t)fr.width * k;

@@ -30,8 +30,9 @@ def test_counting_variant_and_compile_errors(rm):
     assert "no_such_function" in str(e.value)
 
 
-def test_code_objects_are_kept_on_disk_when_asked(rm, tmp_path):
+def test_code_objects_are_kept_on_disk_when_asked(rm, tmp_path, monkeypatch):
     import time
+    monkeypatch.setenv("AMD_COMGR_CACHE", "0")   # the compiler's own cache would make the compiles below as quick as the loads
     src = rm.kernel_source(rm.Scene(scene_path("menger2.txt")))
     rm.set_kernel_cache_dir(str(tmp_path))
     try:
@@ -81,3 +82,34 @@ def test_cache_directory_stays_below_its_limit(rm, tmp_path, monkeypatch):
         assert all(name.startswith("rm_") and name.endswith(".gfx950.bin") for name in left)
     finally:
         rm.set_kernel_cache_dir(None)
+
+
+def test_kernels_are_compiled_by_the_program_beside_the_library(rm):
+    """The library compiles a scene's kernels with rm_jit, a process of its own linked against the ROCm release the library was
+    built with; where that program is switched off (or missing) it compiles in the calling process.  Both accept and refuse
+    the same sources."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(rm.LIB_PATH), "rm_jit")
+    assert os.access(helper, os.X_OK), "raymarching_amd/rm_jit has not been built (make -C raymarching_amd/csrc)"
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import raymarching_amd as rm\n"
+        "rm.set_kernel_cache_dir(None)\n"
+        "src = rm.kernel_source(rm.Scene(%r))\n"
+        "rm.kernel_source_compiles(src)\n"
+        "print(rm.kernel_compiler())\n"
+        "try:\n"
+        "    rm.kernel_source_compiles(src.replace('single_sd<', 'no_such_function<', 1))\n"
+        "except rm.RaymarchError as e:\n"
+        "    print('refused' if 'no_such_function' in str(e) else 'refused without a log')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(rm.__file__))), scene_path("menger2.txt"))
+    for setting, want in ((None, "rm_jit (a process of its own): " + helper), ("off", "hiprtc in this process"),
+                          ("/no/such/program", "hiprtc in this process")):
+        env = dict(os.environ)
+        env.pop("RM_JIT_HELPER", None)
+        if setting is not None:
+            env["RM_JIT_HELPER"] = setting
+        out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.splitlines()[-2:] == [want, "refused"], (setting, out.stdout)
