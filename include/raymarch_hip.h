@@ -338,7 +338,7 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
                      size_t *length);
 int rm_kernel_source_compiles(const char *source);
 /* How this process last obtained the code object of a scene's kernels (a text owned by the library, valid until the calling
- * thread's next call of this function): "rm_jit (a process of its own): <path>" -- the library compiles with the program
+ * thread's next call of this function): "rm_jit, a process of its own: <path>" -- the library compiles with the program
  * rm_jit that is installed beside it, a process of its own linked against the ROCm release the library was built with, so
  * that the kernels do not depend on which other copy of hiprtc the calling process has loaded (PyTorch bundles an older
  * one under the same SONAME; its kernels measure 3-6 % slower); "hiprtc in this process" where that program is missing

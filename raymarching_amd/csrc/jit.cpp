@@ -283,7 +283,7 @@ CodeObject build_code_object(const std::string &source, std::string &log) {
         if (by_helper == 0) return nullptr;
         if (by_helper == 1) {
             std::lock_guard<std::mutex> hold(g_cache_lock);
-            g_compiler_used = "rm_jit (a process of its own): " + helper_path();
+            g_compiler_used = "rm_jit, a process of its own: " + helper_path();
             return code;
         }
     }

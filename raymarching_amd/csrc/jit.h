@@ -45,7 +45,7 @@ void set_kernel_cache_dir(const char *dir);
 bool load_cached_blob(const std::string &kind, const std::string &key, std::vector<uint32_t> &words);
 void store_cached_blob(const std::string &kind, const std::string &key, const std::vector<uint32_t> &words);
 
-// How this process last obtained a code object: "rm_jit (a process of its own): <path>", "hiprtc in this process",
+// How this process last obtained a code object: "rm_jit, a process of its own: <path>", "hiprtc in this process",
 // "none: code object from the cache directory", or "none yet".  The library compiles with the program rm_jit beside it
 // (jit_helper.cpp) when there is one, so that the kernels come from the ROCm release the library was built with whatever
 // other copies of hiprtc the process holds; $RM_JIT_HELPER names another program, "" or "off" compiles in the process.

@@ -104,7 +104,7 @@ def test_kernels_are_compiled_by_the_program_beside_the_library(rm):
         "except rm.RaymarchError as e:\n"
         "    print('refused' if 'no_such_function' in str(e) else 'refused without a log')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(rm.__file__))), scene_path("menger2.txt"))
-    for setting, want in ((None, "rm_jit (a process of its own): " + helper), ("off", "hiprtc in this process"),
+    for setting, want in ((None, "rm_jit, a process of its own: " + helper), ("off", "hiprtc in this process"),
                           ("/no/such/program", "hiprtc in this process")):
         env = dict(os.environ)
         env.pop("RM_JIT_HELPER", None)
