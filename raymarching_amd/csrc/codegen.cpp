@@ -472,13 +472,17 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
          "                                               float (&out_sd)[NP], uint32_t (&out_prim)[NP]) {\n";
     s += emit_body(prog, true);
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
+    // The kernels come in two parts, marked for jit.cpp, which may compile them as two programs side by side: the frame's
+    // kernel (the optimistic scene) and the kernels of the exact scene.
     // rm_trace: launched with 1, 4 or 9 waves per workgroup; rm_trace_refill: one wave (jit.cpp: launch_trace_module)
     char buf[1024];
+    s += "//@part frame\n";
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(576, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
                   "        WorkCounters *counters) {\n    trace_body<CompiledSceneT<%s>, %d, %s>(sc, fr, samples, counters);\n}\n\n",
                   min_waves, counting ? "rm_trace_counting" : "rm_trace", counting ? "true" : "false", points_per_lane, counting ? "true" : "false");
     s += buf;
+    s += "//@part exact\n";
     if (!counting && s.find("exact_wanted_word") != std::string::npos) {
         // the pass behind rm_trace over the tiles it flagged, which can also resolve the sample image into pixels
         // (trace_kernel.h: trace_exact_body); same workgroup shapes.
@@ -490,11 +494,13 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
         s += buf;
     }
     if (refill) {
+        s += "//@part frame\n";
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(64, %d) void %s(const SceneView sc, const FrameView fr, Sample *samples,\n"
                       "        WorkCounters *counters) {\n    trace_refill_body<CompiledSceneT<true>, %s>(sc, fr, samples, counters);\n}\n\n",
                       min_waves, counting ? "rm_trace_refill_counting" : "rm_trace_refill", counting ? "true" : "false");
         s += buf;
+        s += "//@part exact\n";
     }
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(256, %d) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -333,6 +334,7 @@ std::string kernel_compiler_used() {
 
 void SceneModule::unload() {
     if (module) (void)hipModuleUnload(module);
+    if (exact_module) (void)hipModuleUnload(exact_module);
     *this = SceneModule();
 }
 
@@ -387,8 +389,11 @@ bool check_scene_source(const std::string &source, std::string &log) {
     return code != nullptr;
 }
 
-bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
-    out.unload();
+namespace {
+
+// The code object of `source`: from this process's cache, the cache directory, or the compiler.  `seconds`: what that took
+// (0 from the process's cache).
+CodeObject obtain_code(const std::string &source, std::string &log, double &seconds) {
     CodeObject code;
     std::string memory_key = source;   // (the embedded headers cannot change within a process; $RM_JIT_EXTRA can)
     for (const std::string &o : extra_options()) memory_key += "\n//@option " + o;
@@ -397,36 +402,85 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         auto it = g_cache.find(memory_key);
         if (it != g_cache.end()) code = it->second;
     }
-    double seconds = 0.0;
-    if (!code) {
-        const auto t0 = std::chrono::steady_clock::now();
-        code = load_from_disk(source);
-        if (code) {
-            std::lock_guard<std::mutex> hold(g_cache_lock);
-            g_compiler_used = "none: code object from the cache directory";
-        }
-        if (!code) {
-            code = build_code_object(source, log);
-            if (!code) return false;
-            store_to_disk(source, *code);
-        }
-        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    seconds = 0.0;
+    if (code) return code;
+    const auto t0 = std::chrono::steady_clock::now();
+    code = load_from_disk(source);
+    if (code) {
         std::lock_guard<std::mutex> hold(g_cache_lock);
-        if (g_cache.size() >= 256) g_cache.clear();   // a caller that streams ever-new scenes should not grow without bound
-        g_cache.emplace(memory_key, code);
+        g_compiler_used = "none: code object from the cache directory";
+    }
+    if (!code) {
+        code = build_code_object(source, log);
+        if (!code) return nullptr;
+        store_to_disk(source, *code);
+    }
+    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> hold(g_cache_lock);
+    if (g_cache.size() >= 256) g_cache.clear();   // a caller that streams ever-new scenes should not grow without bound
+    g_cache.emplace(memory_key, code);
+    return code;
+}
+
+// The generated source's two parts (codegen.cpp marks them: lines "//@part frame" and "//@part exact" switch between
+// them; what stands before the first mark belongs to both): the frame's kernel, and the kernels of the exact scene.
+// False if the source holds no exact pass -- then one program serves.
+bool split_parts(const std::string &source, std::string &frame, std::string &exact) {
+    if (source.find("rm_trace_exact") == std::string::npos || source.find("//@part frame\n") == std::string::npos) return false;
+    frame.clear();
+    exact.clear();
+    int part = 0;   // 0: both, 1: frame, 2: exact
+    for (size_t at = 0; at < source.size();) {
+        size_t end = source.find('\n', at);
+        end = end == std::string::npos ? source.size() : end + 1;
+        const std::string line = source.substr(at, end - at);
+        at = end;
+        if (line == "//@part frame\n") { part = 1; continue; }
+        if (line == "//@part exact\n") { part = 2; continue; }
+        if (part != 2) frame += line;
+        if (part != 1) exact += line;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
+    out.unload();
+    // With the compiler in processes of its own the two parts compile side by side (inside one process the compiler library
+    // serialises its programs: nothing to gain there).
+    std::string frame_source, exact_source;
+    const bool two = !helper_path().empty() && split_parts(source, frame_source, exact_source);
+    CodeObject code, exact_code;
+    double seconds = 0.0;
+    if (two) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string exact_log;
+        double s0 = 0.0, s1 = 0.0;
+        std::thread other([&] { exact_code = obtain_code(exact_source, exact_log, s1); });
+        code = obtain_code(frame_source, log, s0);
+        other.join();
+        if (!exact_code && code) log = exact_log;
+        if (!code || !exact_code) return false;
+        if (s0 > 0.0 || s1 > 0.0) seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        code = obtain_code(source, log, seconds);
+        if (!code) return false;
     }
     hipError_t e = hipModuleLoadData(&out.module, code->data());
+    if (e == hipSuccess && exact_code) e = hipModuleLoadData(&out.exact_module, exact_code->data());
     if (e != hipSuccess) {
         log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
-        out.module = nullptr;
+        out.unload();
         return false;
     }
+    hipModule_t const exact_from = out.exact_module ? out.exact_module : out.module;
     // a module holds the plain kernel or its work-counting variant (named apart, so that profiles tell them apart)
     const bool counting = source.find("rm_trace_counting") != std::string::npos;
-    const struct { hipFunction_t *fn; const char *name; } symbols[] = { { &out.trace, counting ? "rm_trace_counting" : "rm_trace" },
-                                                                         { &out.eval_sdf, "rm_eval_sdf" } };
+    const struct { hipFunction_t *fn; hipModule_t from; const char *name; } symbols[] = {
+        { &out.trace, out.module, counting ? "rm_trace_counting" : "rm_trace" }, { &out.eval_sdf, exact_from, "rm_eval_sdf" } };
     for (const auto &sym : symbols) {
-        e = hipModuleGetFunction(sym.fn, out.module, sym.name);
+        e = hipModuleGetFunction(sym.fn, sym.from, sym.name);
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(") + sym.name + "): " + hipGetErrorString(e);
             out.unload();
@@ -434,7 +488,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         }
     }
     if (source.find("rm_trace_exact") != std::string::npos) {
-        e = hipModuleGetFunction(&out.trace_exact, out.module, "rm_trace_exact");
+        e = hipModuleGetFunction(&out.trace_exact, exact_from, "rm_trace_exact");
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(rm_trace_exact): ") + hipGetErrorString(e);
             out.unload();
