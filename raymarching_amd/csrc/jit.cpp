@@ -139,6 +139,7 @@ int compile_with_helper(const std::string &source, const std::vector<const char 
     auto cleanup = [&] {
         (void)unlink(src_path.c_str());
         (void)unlink(out_path.c_str());
+        (void)unlink((out_path + ".part").c_str());
         (void)unlink(log_path.c_str());
     };
     size_t written = 0;
@@ -155,11 +156,19 @@ int compile_with_helper(const std::string &source, const std::vector<const char 
     pid_t pid = 0;
     if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) != 0) { cleanup(); return -1; }
     int status = 0;
+    bool reaped = true;
     while (waitpid(pid, &status, 0) < 0) {
-        if (errno != EINTR) { cleanup(); return -1; }
+        if (errno == EINTR) continue;
+        // ECHILD: the calling program ignores SIGCHLD and the child is gone without a status; its code object file is
+        // complete if it exists (the program renames it into place)
+        reaped = false;
+        break;
     }
     int result = -1;
-    if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+    if (!reaped) {
+        code.clear();
+        if (errno == ECHILD && read_whole_file(out_path, code) && !code.empty()) result = 1;
+    } else if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
         code.clear();
         if (read_whole_file(out_path, code) && !code.empty()) result = 1;
     } else if (WIFEXITED(status) && WEXITSTATUS(status) == 2) {

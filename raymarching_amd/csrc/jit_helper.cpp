@@ -71,5 +71,8 @@ int main(int argc, char **argv) {
     std::vector<char> code(size);
     if (hiprtcGetCode(prog, code.data()) != HIPRTC_SUCCESS) return 8;
     (void)hiprtcDestroyProgram(&prog);
-    return write_file(argv[2], code.data(), code.size()) ? 0 : 9;
+    // complete or absent: a caller that cannot learn this program's exit status (SIGCHLD ignored) goes by the file
+    const std::string part = std::string(argv[2]) + ".part";
+    if (!write_file(part, code.data(), code.size())) return 9;
+    return std::rename(part.c_str(), argv[2]) == 0 ? 0 : 10;
 }

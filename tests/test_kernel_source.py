@@ -94,6 +94,8 @@ def test_kernels_are_compiled_by_the_program_beside_the_library(rm):
     assert os.access(helper, os.X_OK), "raymarching_amd/rm_jit has not been built (make -C raymarching_amd/csrc)"
     script = (
         "import sys; sys.path.insert(0, %r)\n"
+        "import os, signal\n"
+        "if os.environ.get('TEST_IGNORE_SIGCHLD'): signal.signal(signal.SIGCHLD, signal.SIG_IGN)\n"
         "import raymarching_amd as rm\n"
         "rm.set_kernel_cache_dir(None)\n"
         "src = rm.kernel_source(rm.Scene(%r))\n"
@@ -104,11 +106,16 @@ def test_kernels_are_compiled_by_the_program_beside_the_library(rm):
         "except rm.RaymarchError as e:\n"
         "    print('refused' if 'no_such_function' in str(e) else 'refused without a log')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(rm.__file__))), scene_path("menger2.txt"))
+    # "ignore": the calling program ignores SIGCHLD, so the library never learns the program's exit status: it goes by the code
+    # object file, and compiles the refused source once more in its own process, which refuses it too
     for setting, want in ((None, "rm_jit, a process of its own: " + helper), ("off", "hiprtc in this process"),
-                          ("/no/such/program", "hiprtc in this process")):
+                          ("/no/such/program", "hiprtc in this process"), ("ignore", None)):
         env = dict(os.environ)
         env.pop("RM_JIT_HELPER", None)
-        if setting is not None:
+        if setting == "ignore":
+            env["TEST_IGNORE_SIGCHLD"] = "1"
+            want = "rm_jit, a process of its own: " + helper
+        elif setting is not None:
             env["RM_JIT_HELPER"] = setting
         out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
