@@ -472,8 +472,8 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
          "                                               float (&out_sd)[NP], uint32_t (&out_prim)[NP]) {\n";
     s += emit_body(prog, true);
     s += "}\n};\n\n}  // namespace rmdev\n\nusing namespace rmdev;\n\n";
-    // The kernels come in two parts, marked for jit.cpp, which may compile them as two programs side by side: the frame's
-    // kernel (the optimistic scene) and the kernels of the exact scene.
+    // The kernels come in parts, marked for jit.cpp, which may compile them as programs of their own side by side: the frame's
+    // kernel (the optimistic scene), the exact pass behind it, and the evaluation of the scene at given points.
     // rm_trace: launched with 1, 4 or 9 waves per workgroup; rm_trace_refill: one wave (jit.cpp: launch_trace_module)
     char buf[1024];
     s += "//@part frame\n";
@@ -502,6 +502,7 @@ std::string generate_scene_source(const HostProgram &prog, int points_per_lane, 
         s += buf;
         s += "//@part exact\n";
     }
+    s += "//@part eval\n";
     std::snprintf(buf, sizeof buf,
                   "extern \"C\" __global__ __launch_bounds__(256, %d) void rm_eval_sdf(const SceneView sc, const float *xyz, uint32_t n, float *sd,\n"
                   "        uint32_t *prim, float *sd_march) {\n    eval_sdf_body<CompiledSceneT<true>>(sc, xyz, n, sd, prim, sd_march);\n}\n", min_waves);

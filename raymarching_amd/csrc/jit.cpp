@@ -285,6 +285,18 @@ void store_to_disk(const std::string &source, const std::vector<char> &code) {
 CodeObject build_code_object(const std::string &source, std::string &log) {
     std::vector<const char *> options = { "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
                                           "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt" };
+    // a part of a split source may ask for a lighter optimisation level (split_parts)
+    std::string level;
+    {
+        const size_t at = source.find("//@optimise ");
+        if (at != std::string::npos && (at == 0 || source[at - 1] == '\n')) {
+            const size_t end = source.find('\n', at);
+            level = source.substr(at + 12, end == std::string::npos ? std::string::npos : end - at - 12);
+        }
+    }
+    if (!level.empty())
+        for (const char *&o : options)
+            if (std::strcmp(o, "-O3") == 0) o = level.c_str();
     const std::vector<std::string> extra = extra_options();
     for (const std::string &o : extra) options.push_back(o.c_str());
     {
@@ -343,7 +355,8 @@ std::string kernel_compiler_used() {
 
 void SceneModule::unload() {
     if (module) (void)hipModuleUnload(module);
-    if (exact_module) (void)hipModuleUnload(exact_module);
+    for (hipModule_t m : more_modules)
+        if (m) (void)hipModuleUnload(m);
     *this = SceneModule();
 }
 
@@ -431,65 +444,95 @@ CodeObject obtain_code(const std::string &source, std::string &log, double &seco
     return code;
 }
 
-// The generated source's two parts (codegen.cpp marks them: lines "//@part frame" and "//@part exact" switch between
-// them; what stands before the first mark belongs to both): the frame's kernel, and the kernels of the exact scene.
-// False if the source holds no exact pass -- then one program serves.
-bool split_parts(const std::string &source, std::string &frame, std::string &exact) {
-    if (source.find("rm_trace_exact") == std::string::npos || source.find("//@part frame\n") == std::string::npos) return false;
-    frame.clear();
-    exact.clear();
-    int part = 0;   // 0: both, 1: frame, 2: exact
+// The generated source's parts (codegen.cpp marks them: the lines "//@part frame", "//@part exact" and "//@part eval" switch
+// between them; what stands before the first mark belongs to all): the frame's kernel, the exact pass behind it, the
+// evaluation at given points.  Parts without a kernel are left out; fewer than two parts: false, one program serves.
+// The exact pass runs over the tiles the frame's kernel marks, as good as never, and is the part that takes longest to
+// compile: it is compiled at -O1 ($RM_EXACT_OPT names another level), a third faster, so that it does not hold the
+// scene's first frame up.
+bool split_parts(const std::string &source, std::vector<std::string> &parts) {
+    parts.clear();
+    if (source.find("//@part frame\n") == std::string::npos) return false;
+    std::string text[3];
+    bool kernel[3] = { false, false, false };
+    int part = -1;   // -1: all
     for (size_t at = 0; at < source.size();) {
         size_t end = source.find('\n', at);
         end = end == std::string::npos ? source.size() : end + 1;
         const std::string line = source.substr(at, end - at);
         at = end;
-        if (line == "//@part frame\n") { part = 1; continue; }
-        if (line == "//@part exact\n") { part = 2; continue; }
-        if (part != 2) frame += line;
-        if (part != 1) exact += line;
+        if (line == "//@part frame\n") { part = 0; continue; }
+        if (line == "//@part exact\n") { part = 1; continue; }
+        if (line == "//@part eval\n") { part = 2; continue; }
+        for (int q = 0; q < 3; q++)
+            if (part < 0 || part == q) text[q] += line;
+        if (part >= 0 && line.find("__global__") != std::string::npos) kernel[part] = true;
     }
-    return true;
+    const char *level = std::getenv("RM_EXACT_OPT");
+    if (!level || !*level) level = "-O1";
+    for (int q = 0; q < 3; q++) {
+        if (!kernel[q]) continue;
+        parts.push_back(q == 1 && std::strcmp(level, "-O3") != 0 ? "//@optimise " + std::string(level) + "\n" + text[q] : text[q]);
+    }
+    return parts.size() >= 2;
 }
 
 }  // namespace
 
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log) {
     out.unload();
-    // With the compiler in processes of its own the two parts compile side by side (inside one process the compiler library
+    // With the compiler in processes of its own the parts compile side by side (inside one process the compiler library
     // serialises its programs: nothing to gain there).
-    std::string frame_source, exact_source;
-    const bool two = !helper_path().empty() && split_parts(source, frame_source, exact_source);
-    CodeObject code, exact_code;
+    std::vector<std::string> parts;
+    if (helper_path().empty() || !split_parts(source, parts)) parts.assign(1, source);
+    std::vector<CodeObject> codes(parts.size());
+    std::vector<std::string> logs(parts.size());
+    std::vector<double> took(parts.size(), 0.0);
     double seconds = 0.0;
-    if (two) {
+    {
         const auto t0 = std::chrono::steady_clock::now();
-        std::string exact_log;
-        double s0 = 0.0, s1 = 0.0;
-        std::thread other([&] { exact_code = obtain_code(exact_source, exact_log, s1); });
-        code = obtain_code(frame_source, log, s0);
-        other.join();
-        if (!exact_code && code) log = exact_log;
-        if (!code || !exact_code) return false;
-        if (s0 > 0.0 || s1 > 0.0) seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    } else {
-        code = obtain_code(source, log, seconds);
-        if (!code) return false;
+        std::vector<std::thread> others;
+        for (size_t q = 1; q < parts.size(); q++) others.emplace_back([&, q] { codes[q] = obtain_code(parts[q], logs[q], took[q]); });
+        codes[0] = obtain_code(parts[0], logs[0], took[0]);
+        for (std::thread &t : others) t.join();
+        bool compiled = false;
+        for (size_t q = 0; q < parts.size(); q++) {
+            if (!codes[q]) {
+                log = logs[q];
+                return false;
+            }
+            compiled = compiled || took[q] > 0.0;
+        }
+        if (compiled) seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    hipError_t e = hipModuleLoadData(&out.module, code->data());
-    if (e == hipSuccess && exact_code) e = hipModuleLoadData(&out.exact_module, exact_code->data());
-    if (e != hipSuccess) {
-        log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
-        out.unload();
-        return false;
+    hipModule_t loaded[3] = { nullptr, nullptr, nullptr };
+    for (size_t q = 0; q < parts.size(); q++) {
+        const hipError_t e = hipModuleLoadData(q == 0 ? &out.module : &out.more_modules[q - 1], codes[q]->data());
+        if (e != hipSuccess) {
+            log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+            out.unload();
+            return false;
+        }
+        loaded[q] = q == 0 ? out.module : out.more_modules[q - 1];
     }
-    hipModule_t const exact_from = out.exact_module ? out.exact_module : out.module;
+    // the module among them that holds a kernel
+    const auto find = [&](hipFunction_t *fn, const char *name) {
+        hipError_t e = hipErrorNotFound;
+        for (hipModule_t m : loaded) {
+            if (!m) continue;
+            e = hipModuleGetFunction(fn, m, name);
+            if (e == hipSuccess) break;
+        }
+        (void)hipGetLastError();
+        return e;
+    };
+    hipError_t e = hipSuccess;
     // a module holds the plain kernel or its work-counting variant (named apart, so that profiles tell them apart)
     const bool counting = source.find("rm_trace_counting") != std::string::npos;
-    const struct { hipFunction_t *fn; hipModule_t from; const char *name; } symbols[] = {
-        { &out.trace, out.module, counting ? "rm_trace_counting" : "rm_trace" }, { &out.eval_sdf, exact_from, "rm_eval_sdf" } };
+    const struct { hipFunction_t *fn; const char *name; } symbols[] = { { &out.trace, counting ? "rm_trace_counting" : "rm_trace" },
+                                                                         { &out.eval_sdf, "rm_eval_sdf" } };
     for (const auto &sym : symbols) {
-        e = hipModuleGetFunction(sym.fn, sym.from, sym.name);
+        e = find(sym.fn, sym.name);
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(") + sym.name + "): " + hipGetErrorString(e);
             out.unload();
@@ -497,7 +540,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
         }
     }
     if (source.find("rm_trace_exact") != std::string::npos) {
-        e = hipModuleGetFunction(&out.trace_exact, exact_from, "rm_trace_exact");
+        e = find(&out.trace_exact, "rm_trace_exact");
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(rm_trace_exact): ") + hipGetErrorString(e);
             out.unload();
@@ -506,7 +549,7 @@ bool compile_scene_module(const std::string &source, uint32_t points_per_lane, S
     }
     if (source.find("rm_trace_refill") != std::string::npos) {
         const char *name = counting ? "rm_trace_refill_counting" : "rm_trace_refill";
-        e = hipModuleGetFunction(&out.trace_refill, out.module, name);
+        e = find(&out.trace_refill, name);
         if (e != hipSuccess) {
             log = std::string("hipModuleGetFunction(") + name + "): " + hipGetErrorString(e);
             out.unload();

@@ -20,7 +20,7 @@ extern const unsigned kEmbeddedHeaderCount;
 // One loaded code object with the kernels generated for one scene.
 struct SceneModule {
     hipModule_t module = nullptr;
-    hipModule_t exact_module = nullptr;     // trace_exact and eval_sdf, where the two parts were compiled as two programs
+    hipModule_t more_modules[2] = { nullptr, nullptr };   // where the source's parts were compiled as programs of their own
     hipFunction_t trace = nullptr;
     hipFunction_t trace_exact = nullptr;    // the pass over the tiles `trace` flagged (null in work-counting modules: their walks are exact)
     hipFunction_t trace_refill = nullptr;   // null unless the source holds it
