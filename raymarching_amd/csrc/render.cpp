@@ -33,12 +33,21 @@ std::string g_error;
 void *g_pinned = nullptr;
 size_t g_pinned_bytes = 0;
 
+void *g_refused = nullptr;       // the last buffer that could not be locked: not tried again frame after frame
+size_t g_refused_bytes = 0;
+
 void pin(void *image, size_t bytes) {
     if (image == g_pinned && bytes <= g_pinned_bytes) return;   // the same buffer asked for more (float after 8-bit frames) is locked anew
+    if (image == g_refused && bytes == g_refused_bytes) return;
     unpin();
-    if (rm_host_register(image, bytes) == RM_OK) {   // a buffer that cannot be locked still works, more slowly
+    // a buffer that cannot be locked still works, more slowly; one that is page-locked already (rm_host_alloc) is refused
+    // here too, and rendered into as fast as a registered one
+    if (rm_host_register(image, bytes) == RM_OK) {
         g_pinned = image;
         g_pinned_bytes = bytes;
+    } else {
+        g_refused = image;
+        g_refused_bytes = bytes;
     }
 }
 
@@ -64,6 +73,8 @@ void unpin(void) {
     if (g_pinned) (void)rm_host_unregister(g_pinned);
     g_pinned = nullptr;
     g_pinned_bytes = 0;
+    g_refused = nullptr;
+    g_refused_bytes = 0;
 }
 
 void setup::devices(const int *device_ids, unsigned count) {
