@@ -119,3 +119,22 @@ def test_cameras_that_need_the_exact_kernel(rm, iterations, camera, whole):
     assert tiles > 0 and tiles % 2 == 0
     if whole:
         assert tiles == 2 * (96 * 2 // 8) * (64 * 2 // 8)
+
+
+def test_kernels_come_from_the_program_beside_the_library(rm, tmp_path):
+    """A scene no cache has seen: its kernels are compiled by rm_jit (three programs side by side, three modules), the code
+    objects land in the cache directory, and a second context finds them in the process's cache; the frame is the record
+    walker's either way."""
+    kw = dict(width=64, height=48, kernel=3)
+    text = INSIDE.replace("MengerSponge 0.0 10.0 -50.0 20.0 4", "MengerSponge 0.25 10.0 -50.0 20.0 3").replace("9.9 19.9 -40.1", "30.0 25.0 -20.0")
+    rm.set_kernel_cache_dir(str(tmp_path))
+    try:
+        scene = rm.Scene(text=text)
+        (gpu,), _ = _render(rm, scene, True, **kw)
+        assert rm.kernel_compiler().startswith("rm_jit, a process of its own: "), rm.kernel_compiler()
+        assert len([f for f in tmp_path.iterdir() if f.name.endswith(".gfx950.bin")]) >= 3   # frame, exact pass, point evaluation
+        (again,), _ = _render(rm, scene, True, **kw)
+        (walked,), _ = _render(rm, scene, False, **kw)
+        assert gpu.tobytes() == walked.tobytes() and again.tobytes() == walked.tobytes()
+    finally:
+        rm.set_kernel_cache_dir(None)
