@@ -150,7 +150,18 @@ int compile_with_helper(const std::string &source, const std::vector<const char 
     }
     (void)close(fd);
     if (written != source.size()) { cleanup(); return -1; }
-    std::vector<char *> argv = { const_cast<char *>(helper.c_str()), const_cast<char *>(src_path.c_str()), const_cast<char *>(out_path.c_str()) };
+    // the program checks that it was built with the device headers this library holds
+    static const std::string digest = [] {
+        unsigned long long h = 1469598103934665603ull;
+        for (unsigned i = 0; i < kEmbeddedHeaderCount; i++)
+            for (const char *text : { kEmbeddedHeaders[i].name, kEmbeddedHeaders[i].text })
+                for (const char *c = text; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        char hex[32];
+        std::snprintf(hex, sizeof hex, "%016llx", h);
+        return std::string(hex);
+    }();
+    std::vector<char *> argv = { const_cast<char *>(helper.c_str()), const_cast<char *>(digest.c_str()), const_cast<char *>(src_path.c_str()),
+                                 const_cast<char *>(out_path.c_str()) };
     for (const char *o : options) argv.push_back(const_cast<char *>(o));
     argv.push_back(nullptr);
     pid_t pid = 0;

@@ -1,6 +1,6 @@
 // jit_helper.cpp -- rm_jit: compiles one kernel source with hiprtc in a process of its own.
 //
-//   rm_jit <source file> <code object file> [compiler option ...]
+//   rm_jit <digest of the device headers> <source file> <code object file> [compiler option ...]
 //
 // The library starts it for every scene whose kernels it has to compile (jit.cpp).  A process that holds other ROCm
 // libraries -- PyTorch ships its own hiprtc and code-object manager under the same SONAMEs, an older release than the
@@ -8,7 +8,8 @@
 // against the ROCm installation it was built with, so the kernels are always that compiler's (measured: 3 % faster
 // on the shipped frame, 6 % on a 1024-primitive scene, than the release bundled with PyTorch 2.10 makes them).
 // Exit status: 0 = code object written; 2 = the compiler refused the source, its log is in "<code object file>.log";
-// anything else = the program could not do its work (the library then compiles in its own process).
+// 11 = this program was built with other device headers than the library that started it (the digest differs: one of
+// the two is stale); anything else = the program could not do its work.  The library then compiles in its own process.
 #include <hip/hiprtc.h>
 
 #include <cstdio>
@@ -44,10 +45,22 @@ bool write_file(const std::string &path, const char *data, size_t bytes) {
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 3) {
-        std::fprintf(stderr, "usage: rm_jit <source file> <code object file> [compiler option ...]\n");
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: rm_jit <digest of the device headers> <source file> <code object file> [compiler option ...]\n");
         return 3;
     }
+    {
+        // the headers compiled into this program must be the ones the library generated the source for (FNV-1a, as jit.cpp)
+        unsigned long long h = 1469598103934665603ull;
+        for (unsigned i = 0; i < rmdev::kEmbeddedHeaderCount; i++)
+            for (const char *text : { rmdev::kEmbeddedHeaders[i].name, rmdev::kEmbeddedHeaders[i].text })
+                for (const char *c = text; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        char mine[32];
+        std::snprintf(mine, sizeof mine, "%016llx", h);
+        if (std::string(mine) != argv[1]) return 11;
+    }
+    argv++;
+    argc--;
     std::string source;
     if (!read_file(argv[1], source)) return 4;
     std::vector<const char *> texts, names;

@@ -92,6 +92,8 @@ def test_kernels_are_compiled_by_the_program_beside_the_library(rm):
     import sys
     helper = os.path.join(os.path.dirname(rm.LIB_PATH), "rm_jit")
     assert os.access(helper, os.X_OK), "raymarching_amd/rm_jit has not been built (make -C raymarching_amd/csrc)"
+    # a program built with other device headers than the library's refuses to compile for it (the library then compiles itself)
+    assert subprocess.run([helper, "0123456789abcdef", os.devnull, os.devnull]).returncode == 11
     script = (
         "import sys; sys.path.insert(0, %r)\n"
         "import os, signal\n"
