@@ -7,6 +7,6 @@ the binding without the built library raises.
 """
 from .binding import (  # noqa: F401
     LIB_PATH, Node, Params, Rows, Counters, Scene, Renderer, RaymarchError,
-    default_params, exported_symbols, HostBuffer, kernel_source, kernel_source_compiles, kernel_compiler, set_kernel_cache_dir, lib, write_png,
+    default_params, exported_symbols, HostBuffer, kernel_source, kernel_source_compiles, kernel_compiler, precompile, set_kernel_cache_dir, lib, write_png,
     MultiRenderer, MULTI_AUTO, MULTI_RCCL, MULTI_COPY, MULTI_DIRECT,
 )

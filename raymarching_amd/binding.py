@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(os.path.dirname(os.path
 # every symbol include/raymarch_hip.h declares
 EXPORTS = (
     "rm_create", "rm_destroy", "rm_set_params", "rm_reserve", "rm_set_scene", "rm_render_rgba8", "rm_render_f32",
-    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_set_row_placement", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_kernel_compiler", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_set_slot_stats", "rm_get_slot_stats", "rm_get_exact_tiles", "rm_stream", "rm_last_error",
+    "rm_render_device", "rm_enqueue_host", "rm_host_alloc", "rm_host_free", "rm_host_register", "rm_host_unregister", "rm_set_band_list", "rm_set_row_placement", "rm_enqueue_device", "rm_enqueue_device_static", "rm_static_scratch_bytes", "rm_wait", "rm_set_stream", "rm_eval_sdf", "rm_eval_sdf_both", "rm_kernel_source", "rm_kernel_source_compiles", "rm_kernel_compiler", "rm_precompile_scene", "rm_set_kernel_cache_dir", "rm_set_evaluator", "rm_set_kernel_mode", "rm_set_tile_scheduling", "rm_set_shading", "rm_set_lane_refill", "rm_get_tile_costs", "rm_set_counting", "rm_get_counters", "rm_set_slot_stats", "rm_get_slot_stats", "rm_get_exact_tiles", "rm_stream", "rm_last_error",
     "rm_scene_load", "rm_scene_parse", "rm_scene_free", "rm_scene_node_count", "rm_scene_light_count",
     "rm_scene_nodes", "rm_scene_lights", "rm_scene_camera", "rm_set_scene_from", "rm_write_png",
     "rm_multi_create", "rm_multi_destroy", "rm_multi_set_params", "rm_multi_set_scene", "rm_multi_set_scene_from",
@@ -101,6 +101,7 @@ def lib():
     L.rm_kernel_source.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rm_kernel_source_compiles.argtypes = [C.c_char_p]
     L.rm_kernel_compiler.restype = C.c_char_p
+    L.rm_precompile_scene.argtypes = [vp, C.c_uint32, C.c_int]
     L.rm_set_kernel_cache_dir.argtypes = [C.c_char_p]
     L.rm_set_kernel_mode.argtypes = [vp, C.c_int]
     L.rm_set_tile_scheduling.argtypes = [vp, C.c_int]
@@ -210,6 +211,12 @@ def kernel_source(scene, lattice=True, counting=False):
     buf = C.create_string_buffer(n.value + 1)
     _check(lib().rm_kernel_source(arr, len(arr), 1 if lattice else 0, int(counting), buf, n.value + 1, C.byref(n)), "rm_kernel_source")
     return buf.value.decode()
+
+
+def precompile(scene, lattice=True):
+    """Starts compiling the kernels a Renderer.set_scene(scene) will want and returns at once (rm_precompile_scene)."""
+    arr = scene.nodes()
+    _check(lib().rm_precompile_scene(arr, len(arr), 1 if lattice else 0), "rm_precompile_scene")
 
 
 def set_kernel_cache_dir(path):

@@ -1160,6 +1160,14 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
     return RM_OK;
 }
 
+int rm_precompile_scene(const rm_node *nodes, uint32_t n_nodes, int evaluator) {
+    std::string why;
+    rmdev::HostProgram prog;
+    if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_precompile_scene: " + why);
+    rmdev::precompile_scene_source(rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, false, std::getenv("RM_REFILL") != nullptr));
+    return RM_OK;
+}
+
 int rm_set_kernel_cache_dir(const char *directory) {
     rmdev::set_kernel_cache_dir(directory);
     return RM_OK;

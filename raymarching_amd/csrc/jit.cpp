@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -35,6 +36,10 @@ namespace {
 using CodeObject = std::shared_ptr<const std::vector<char>>;
 std::mutex g_cache_lock;
 std::unordered_map<std::string, CodeObject> g_cache;   // source text and $RM_JIT_EXTRA -> gfx950 code object
+// compiles started ahead of their use (precompile_scene_source), by the same key; declared behind the cache they fill, so
+// that at the end of the process they are waited for while it still exists
+struct Compiled { CodeObject code; std::string log; };
+std::unordered_map<std::string, std::shared_future<Compiled>> g_in_flight;
 std::string g_cache_dir;                                // second level on disk ("" = none)
 bool g_cache_dir_chosen = false;                        // set_kernel_cache_dir was called, or the default was looked up
 
@@ -108,12 +113,13 @@ std::string find_helper() {
     return access(path.c_str(), X_OK) == 0 ? path : "";
 }
 
+// (Never destroyed, like the other texts below that a background compile may still read while the process ends.)
 const std::string &helper_path() {
-    static const std::string path = find_helper();
+    static const std::string &path = *new std::string(find_helper());
     return path;
 }
 
-std::string g_compiler_used = "none yet";   // how this process last obtained a code object (kernel_compiler_used)
+std::string &g_compiler_used = *new std::string("none yet");   // how this process last obtained a code object (kernel_compiler_used)
 
 bool read_whole_file(const std::string &path, std::vector<char> &out) {
     std::FILE *f = std::fopen(path.c_str(), "rb");
@@ -151,7 +157,7 @@ int compile_with_helper(const std::string &source, const std::vector<const char 
     (void)close(fd);
     if (written != source.size()) { cleanup(); return -1; }
     // the program checks that it was built with the device headers this library holds
-    static const std::string digest = [] {
+    static const std::string &digest = *new std::string([] {
         unsigned long long h = 1469598103934665603ull;
         for (unsigned i = 0; i < kEmbeddedHeaderCount; i++)
             for (const char *text : { kEmbeddedHeaders[i].name, kEmbeddedHeaders[i].text })
@@ -159,7 +165,7 @@ int compile_with_helper(const std::string &source, const std::vector<const char 
         char hex[32];
         std::snprintf(hex, sizeof hex, "%016llx", h);
         return std::string(hex);
-    }();
+    }());
     std::vector<char *> argv = { const_cast<char *>(helper.c_str()), const_cast<char *>(digest.c_str()), const_cast<char *>(src_path.c_str()),
                                  const_cast<char *>(out_path.c_str()) };
     for (const char *o : options) argv.push_back(const_cast<char *>(o));
@@ -424,21 +430,15 @@ bool check_scene_source(const std::string &source, std::string &log) {
 
 namespace {
 
-// The code object of `source`: from this process's cache, the cache directory, or the compiler.  `seconds`: what that took
-// (0 from the process's cache).
-CodeObject obtain_code(const std::string &source, std::string &log, double &seconds) {
-    CodeObject code;
-    std::string memory_key = source;   // (the embedded headers cannot change within a process; $RM_JIT_EXTRA can)
-    for (const std::string &o : extra_options()) memory_key += "\n//@option " + o;
-    {
-        std::lock_guard<std::mutex> hold(g_cache_lock);
-        auto it = g_cache.find(memory_key);
-        if (it != g_cache.end()) code = it->second;
-    }
-    seconds = 0.0;
-    if (code) return code;
-    const auto t0 = std::chrono::steady_clock::now();
-    code = load_from_disk(source);
+std::string memory_key_of(const std::string &source) {
+    std::string key = source;   // (the embedded headers cannot change within a process; $RM_JIT_EXTRA can)
+    for (const std::string &o : extra_options()) key += "\n//@option " + o;
+    return key;
+}
+
+// The code object of `source` from the cache directory or the compiler, into this process's cache.
+CodeObject compile_now(const std::string &source, const std::string &memory_key, std::string &log) {
+    CodeObject code = load_from_disk(source);
     if (code) {
         std::lock_guard<std::mutex> hold(g_cache_lock);
         g_compiler_used = "none: code object from the cache directory";
@@ -448,12 +448,63 @@ CodeObject obtain_code(const std::string &source, std::string &log, double &seco
         if (!code) return nullptr;
         store_to_disk(source, *code);
     }
-    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::lock_guard<std::mutex> hold(g_cache_lock);
     if (g_cache.size() >= 256) g_cache.clear();   // a caller that streams ever-new scenes should not grow without bound
     g_cache.emplace(memory_key, code);
     return code;
 }
+
+// The code object of `source`: from this process's cache, from a compile started ahead of time, from the cache directory, or
+// from the compiler.  `seconds`: what that took (0 from the process's cache).
+CodeObject obtain_code(const std::string &source, std::string &log, double &seconds) {
+    const std::string memory_key = memory_key_of(source);
+    std::shared_future<Compiled> started;
+    {
+        std::lock_guard<std::mutex> hold(g_cache_lock);
+        auto it = g_cache.find(memory_key);
+        if (it != g_cache.end()) {
+            seconds = 0.0;
+            return it->second;
+        }
+        auto f = g_in_flight.find(memory_key);
+        if (f != g_in_flight.end()) started = f->second;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    CodeObject code;
+    if (started.valid()) {
+        const Compiled &done = started.get();   // (waits for it)
+        code = done.code;
+        if (!code) log = done.log;
+        std::lock_guard<std::mutex> hold(g_cache_lock);
+        g_in_flight.erase(memory_key);
+    }
+    if (!code) code = compile_now(source, memory_key, log);
+    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return code;
+}
+
+bool split_parts(const std::string &source, std::vector<std::string> &parts);
+
+}  // namespace
+
+void precompile_scene_source(const std::string &source) {
+    std::vector<std::string> parts;
+    if (helper_path().empty()) return;   // in this process the compiler would only compete with the caller's own work
+    if (!split_parts(source, parts)) parts.assign(1, source);
+    for (const std::string &part : parts) {
+        const std::string memory_key = memory_key_of(part);
+        std::lock_guard<std::mutex> hold(g_cache_lock);
+        if (g_cache.count(memory_key) || g_in_flight.count(memory_key)) continue;
+        if (g_in_flight.size() >= 64) return;   // a caller that announces scenes and never uses them
+        g_in_flight.emplace(memory_key, std::async(std::launch::async, [part, memory_key] {
+                                            Compiled out;
+                                            out.code = compile_now(part, memory_key, out.log);
+                                            return out;
+                                        }).share());
+    }
+}
+
+namespace {
 
 // The generated source's parts (codegen.cpp marks them: the lines "//@part frame", "//@part exact" and "//@part eval" switch
 // between them; what stands before the first mark belongs to all): the frame's kernel, the exact pass behind it, the

@@ -36,6 +36,11 @@ struct SceneModule {
 // Returns false and fills `log` on failure.
 bool compile_scene_module(const std::string &source, uint32_t points_per_lane, SceneModule &out, std::string &log);
 
+// Starts the compile of `source` (its parts) in the background, where the compiler runs in processes of its own: a later
+// compile_scene_module of the same source waits for it instead of starting its own.  For callers that know the scene before
+// they have a device context (the compile then overlaps the device's initialisation).
+void precompile_scene_source(const std::string &source);
+
 // Second-level cache of code objects on disk.  Default: $RM_KERNEL_CACHE_DIR ("" or "off": none), else the first of
 // $XDG_CACHE_HOME/raymarch_hip, $HOME/.cache/raymarch_hip, /tmp/raymarch_hip-<uid> that is (or can be made) a directory
 // of the calling user's that nobody else can write; set_kernel_cache_dir overrides (null or "": none).  Files are keyed

@@ -87,6 +87,12 @@ void setup::context(void) {
     else if (g_ctx) rm_destroy(g_ctx);
     g_multi = nullptr;
     g_ctx = nullptr;
+    // a scene loaded already (the reference's main.cpp loads it first, main.cpp:22-32): its kernels start compiling now,
+    // while the device is initialised
+    if (scene::current().tree) {
+        const std::vector<rm_node> nodes = scene::current().nodes();
+        (void)rm_precompile_scene(nodes.data(), static_cast<uint32_t>(nodes.size()), RM_EVAL_LATTICE);
+    }
     if (g_devices.size() == 1) return report(rm_create(g_devices[0], &g_ctx), "Failed to create HIP context");
     report(rm_multi_create(g_devices.data(), (uint32_t)g_devices.size(), RM_MULTI_AUTO, &g_multi), "Failed to create HIP contexts");
     if (g_multi) g_ctx = rm_multi_context(g_multi, 0);

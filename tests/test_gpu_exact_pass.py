@@ -138,3 +138,24 @@ def test_kernels_come_from_the_program_beside_the_library(rm, tmp_path):
         assert gpu.tobytes() == walked.tobytes() and again.tobytes() == walked.tobytes()
     finally:
         rm.set_kernel_cache_dir(None)
+
+
+def test_compile_started_ahead_of_the_context(rm, tmp_path):
+    """rm_precompile_scene: the compile of a scene's kernels starts before there is a context; rm_set_scene waits for it
+    instead of compiling (every code object in the cache directory was written once), and the frame is the record walker's."""
+    kw = dict(width=64, height=48, kernel=2)
+    text = INSIDE.replace("MengerSponge 0.0 10.0 -50.0 20.0 4", "MengerSponge 0.5 10.0 -50.0 20.0 3").replace("9.9 19.9 -40.1", "31.0 25.0 -20.0")
+    rm.set_kernel_cache_dir(str(tmp_path))
+    try:
+        scene = rm.Scene(text=text)
+        rm.precompile(scene)
+        rm.precompile(scene)                      # a second announcement starts nothing new
+        (gpu,), _ = _render(rm, scene, True, **kw)
+        objects = sorted(f.name for f in tmp_path.iterdir() if f.name.endswith(".gfx950.bin"))
+        assert len(objects) == 3, objects
+        (walked,), _ = _render(rm, scene, False, **kw)
+        assert gpu.tobytes() == walked.tobytes()
+        with pytest.raises(rm.RaymarchError):
+            rm.lib() and rm.binding._check(rm.lib().rm_precompile_scene(None, 0, 1), "rm_precompile_scene")
+    finally:
+        rm.set_kernel_cache_dir(None)
