@@ -339,7 +339,7 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
 int rm_kernel_source_compiles(const char *source);
 /* Starts compiling the kernels rm_set_scene will want for this scene (default settings: RM_KERNEL_COMPILED, compact rows)
  * and returns at once; needs no context.  A later rm_set_scene of the same nodes with the same evaluator waits for these
- * compiles instead of starting its own.  For callers that know the scene before they have a context: called ahead of
+ * compiles instead of starting its own (a scene that does not compile is reported there, not here).  For callers that know the scene before they have a context: called ahead of
  * rm_create, the compile (0.65 s for the shipped scene) runs while the device is initialised (0.12 s).  Does nothing where the
  * compiler runs inside the calling process (see rm_kernel_compiler).  No counterpart in the reference. */
 int rm_precompile_scene(const rm_node *nodes, uint32_t n_nodes, int evaluator);

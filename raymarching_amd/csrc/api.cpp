@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1161,10 +1162,25 @@ int rm_kernel_source(const rm_node *nodes, uint32_t n_nodes, int evaluator, int 
 }
 
 int rm_precompile_scene(const rm_node *nodes, uint32_t n_nodes, int evaluator) {
-    std::string why;
-    rmdev::HostProgram prog;
-    if (!rmdev::compile_scene(nodes, n_nodes, evaluator == RM_EVAL_LATTICE, prog, why)) return fail(RM_ERR_INVALID, "rm_precompile_scene: " + why);
-    rmdev::precompile_scene_source(rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, false, std::getenv("RM_REFILL") != nullptr));
+    if (!nodes || n_nodes == 0) return fail(RM_ERR_INVALID, "rm_precompile_scene: no nodes");
+    // Everything in the background, the scene's host half too (tables and source of a Menger-6 scene take a quarter of a
+    // second): the caller goes on to create its context.  A scene that does not compile is rm_set_scene's to report.
+    static std::mutex lock;
+    static std::vector<std::future<void>> &running = *new std::vector<std::future<void>>();   // (never destroyed: see jit.cpp)
+    std::vector<rm_node> copy(nodes, nodes + n_nodes);
+    const bool refill = std::getenv("RM_REFILL") != nullptr;
+    std::lock_guard<std::mutex> hold(lock);
+    for (size_t i = 0; i < running.size();) {
+        if (running[i].wait_for(std::chrono::seconds(0)) == std::future_status::ready) running.erase(running.begin() + (long)i);
+        else i++;
+    }
+    if (running.size() >= 8) return RM_OK;   // enough announced scenes on their way
+    running.push_back(std::async(std::launch::async, [copy = std::move(copy), evaluator, refill] {
+        std::string why;
+        rmdev::HostProgram prog;
+        if (!rmdev::compile_scene(copy.data(), (uint32_t)copy.size(), evaluator == RM_EVAL_LATTICE, prog, why)) return;
+        rmdev::precompile_scene_source(rmdev::generate_scene_source(prog, kCompiledPts, kCompiledWaves, false, refill));
+    }));
     return RM_OK;
 }
 
