@@ -1166,7 +1166,7 @@ int rm_precompile_scene(const rm_node *nodes, uint32_t n_nodes, int evaluator) {
     // Everything in the background, the scene's host half too (tables and source of a Menger-6 scene take a quarter of a
     // second): the caller goes on to create its context.  A scene that does not compile is rm_set_scene's to report.
     static std::mutex lock;
-    static std::vector<std::future<void>> &running = *new std::vector<std::future<void>>();   // (never destroyed: see jit.cpp)
+    static std::vector<std::future<void>> running;   // (waited for when the process ends: made late, so destroyed early)
     std::vector<rm_node> copy(nodes, nodes + n_nodes);
     const bool refill = std::getenv("RM_REFILL") != nullptr;
     std::lock_guard<std::mutex> hold(lock);
