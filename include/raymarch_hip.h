@@ -417,10 +417,10 @@ int rm_set_scene_from(rm_context *ctx, const rm_scene *scene);
  *
  * The reference's render::GPU (render.cpp:468-475) drives one device.  An rm_multi owns one rendering context
  * per entry of `devices` (its ranks), deals the frame's row bands to them cyclically (band b of RM_MULTI_BAND_ROWS
- * rows belongs to rank b mod n; every pixel is independent, render.cpp:122-129), has every rank render its share
- * into its own device memory, and gathers the shares into one frame on rank 0's device -- the one exchange step of
- * the path -- from where the frame goes to the caller.  The gathered frame equals the frame one context renders,
- * bit for bit.
+ * rows belongs to rank b mod n; every pixel is independent, render.cpp:122-129) and has the frame end up on rank 0's
+ * device, from where it goes to the caller: either every rank stores its rows there itself, or every rank renders its
+ * share into its own device memory and the shares are gathered -- the one exchange step of the path.  The frame
+ * equals the frame one context renders, bit for bit.
  *   transport  RM_MULTI_RCCL   grouped ncclSend / ncclRecv of every rank's share to rank 0 over xGMI (librccl is
  *                              loaded when the first such object is created; one communicator per rank from
  *                              ncclCommInitAll), then a de-interleaving copy on rank 0's device;
