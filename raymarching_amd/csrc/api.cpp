@@ -858,10 +858,14 @@ int rm_reserve(rm_context *ctx) {
     RM_HIP(hipMemsetAsync(ctx->d_frame_f32.ptr, 0, pixels * 4 * sizeof(float), ctx->stream));
     if (!writes_pixels) RM_HIP(hipMemsetAsync(ctx->d_samples.ptr, 0, samples * sizeof(rmdev::Sample), ctx->stream));
     RM_HIP(hipMemsetAsync(ctx->d_tile_cost.ptr, 0, tiles * sizeof(uint32_t), ctx->stream));
-    // ... and the first copy in either direction between page-locked host memory and the device sets up the copy path (6 ms measured)
+    // ... and the first copy between page-locked host memory and the device sets up the copy path (6 ms measured).  Out of
+    // the device first, directly behind the fills: a copy queued behind another copy rides on that one's engine, and the
+    // first frame's copy of the tile costs -- behind kernels -- would then pay for the outward engine's set-up itself (ROCm
+    // 7.2's runtime; the one bundled with PyTorch 2.10 does not care).
+    RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(hipStreamSynchronize(ctx->stream));
     std::memset(ctx->h_tiles.ptr, 0, tiles * sizeof(uint32_t));
     RM_HIP(hipMemcpyAsync(ctx->d_tile_order.ptr, ctx->h_tiles.ptr, tiles * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    RM_HIP(hipMemcpyAsync(ctx->h_tiles.ptr, ctx->d_tile_cost.ptr, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(hipStreamSynchronize(ctx->stream));
     return preload_tile_order(ctx);
 }
